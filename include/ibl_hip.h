@@ -1,0 +1,130 @@
+/*
+ * ibl_hip.h -- C ABI of the MI355X (gfx950) image-based-lighting precompute library.
+ *
+ * The reference tool (src/utilities/cube.cpp) has no plugin or FFI interface: its
+ * seams are three free functions, two codec functions and a box filter inside
+ * main().  Each entry point below replaces one of those seams and says which.
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a non-zero IBL_E* code otherwise;
+ *     nothing throws across this boundary.  ibl_last_error() returns the message
+ *     of the calling thread's last failure (the reference would PANIC,
+ *     include/util.hpp:25).
+ *   - A cube map is a face-major vertical strip of RGBA float32 texels,
+ *     index ((face*H + y)*W + x)*4, faces +X,-X,+Y,-Y,+Z,-Z
+ *     (cube.cpp:16-29,96).  Faces are square (the reference strides input rows by
+ *     the height, cube.cpp:104,264, so nothing else is meaningful).
+ *   - "*_dev" functions take DEVICE pointers, enqueue on `stream` (a hipStream_t;
+ *     NULL = the library's own stream) and do not synchronise.  They use a
+ *     per-device workspace the library owns, so calls on one device must not
+ *     overlap in time.
+ *   - The functions without the suffix take HOST pointers, copy in, run, copy out
+ *     and block; they are what a C++ host that used to call the reference
+ *     functions calls instead.
+ *   - [out_begin, out_begin+out_count) selects output texels in (face, y, x)
+ *     order (cells for the LUT); only those are written.  One process per GPU
+ *     shards a bake this way and gathers the slices afterwards.
+ */
+#ifndef IBL_HIP_H
+#define IBL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    IBL_OK = 0,
+    IBL_EINVAL = 1,     /* bad size / range / null pointer               */
+    IBL_ENODEV = 2,     /* no usable gfx950 device, or ibl_init not called */
+    IBL_EHIP = 3,       /* a HIP runtime call failed (message has details) */
+    IBL_ENOMEM = 4
+};
+
+/* BRDF-table jitter modes (cube.cpp:342-344,366 draws from std::mt19937 seeded by
+ * std::random_device; the seed is explicit here). */
+enum {
+    IBL_LUT_JITTER_COUNTER = 1,  /* counter-based hash of (seed, cell, sample)   */
+    IBL_LUT_JITTER_MIDPOINT = 2  /* stratum midpoints: deterministic quadrature  */
+};
+
+/* ---- life cycle ---------------------------------------------------------- */
+
+/* Binds the calling process to HIP device `device` (-1: the current device),
+ * creates the library stream.  Fails with IBL_ENODEV when no GPU is present:
+ * there is no CPU fallback behind this library. */
+int ibl_init(int device);
+int ibl_shutdown(void);
+const char* ibl_last_error(void);
+int ibl_device_count(void);
+
+/* ---- level geometry (host arithmetic only) ------------------------------- */
+
+/* cube.cpp:147: floor(log2(max(w,h)) - log2(min_size)). */
+uint32_t ibl_ggx_mip_levels(uint32_t top_w, uint32_t top_h, uint32_t min_size);
+/* cube.cpp:161-170,175: roughness, alpha^2, cutoff and patch size of one level. */
+int ibl_ggx_level_params(uint32_t mip_level, uint32_t mip_levels, uint32_t in_w, uint32_t in_h,
+                         float* roughness, float* alpha2, float* cutoff, uint32_t* patch_size);
+
+/* ---- device-resident entry points ---------------------------------------- */
+
+/* integrateLambertian's texel loop, cube.cpp:95-129 (no encode, no file). */
+int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
+                       uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
+
+/* One iteration of integrateGGX's level loop, cube.cpp:152-309 (no encode, no
+ * file).  Rejects min(in_w,in_h) < 16, where the reference divides by a zero
+ * patch size (cube.cpp:175,182). */
+int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                      uint32_t mip_level, uint32_t mip_levels,
+                      uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
+
+/* generateGGXLUT's cell loop, cube.cpp:346-385 (no printing): d_out is
+ * [n_rough][n_cos][2] float32 (slope, bias). */
+int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
+                     uint32_t cell_begin, uint32_t cell_count, float* d_out, void* stream);
+
+/* convertRGBEtoRGB / convertRGBtoRGBE, src/util.cpp:93-145, n texels. */
+int ibl_rgbe_decode_dev(const uint8_t* d_rgbe, float* d_rgba, uint32_t n, void* stream);
+int ibl_rgbe_encode_dev(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, void* stream);
+
+/* The box filter of main, cube.cpp:482-501: (w x 6h) strip -> (w/d x 6h/d). */
+int ibl_downscale_dev(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, void* stream);
+
+/* ---- host-buffer entry points -------------------------------------------- */
+
+int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* out);
+int ibl_ggx_level(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                  uint32_t mip_level, uint32_t mip_levels, float* out);
+int ibl_brdf_lut(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
+                 float* out_slope_bias);
+int ibl_rgbe_decode(const uint8_t* rgbe, float* rgba, uint32_t n);
+int ibl_rgbe_encode(const float* rgba, uint8_t* rgbe, uint32_t n);
+int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* out);
+
+/* The whole bake of main, cube.cpp:457-514, with the input resident on the device
+ * across all steps: RGBE strip in, RGBE strips out.  rgbe_in is w x 6w x 4 bytes.
+ * lambertian_out (may be NULL) receives cubemap_size^2*6*4 bytes; ggx_out (may be
+ * NULL) receives the levels 1..mip_levels back to back, level m being
+ * (w>>m)^2*6*4 bytes.  mip sizes derive from the pre-downscale width
+ * (cube.cpp:473-474,513). */
+int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
+                  uint8_t* lambertian_out, uint8_t* ggx_out);
+
+/* ---- measurement ---------------------------------------------------------- */
+
+/* When enabled, every *_dev call brackets its dominant kernel with HIP events on
+ * the stream it was launched on. */
+int ibl_set_timing(int enabled);
+/* Waits for the last bracketed kernel and returns its duration in ms. */
+int ibl_last_kernel_ms(float* ms);
+/* Work done by the last lambertian/ggx *_dev call as the kernels counted it
+ * (GGX counts need ibl_set_counting(1); they cost a few percent). */
+int ibl_set_counting(int enabled);
+int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBL_HIP_H */

@@ -1,0 +1,281 @@
+"""ctypes binding of ``libibl_hip.so`` (C ABI: ``include/ibl_hip.h``).
+
+This is plumbing for the tests and the benchmark: torch supplies device memory
+and streams, every computation happens inside the HIP library.  Nothing here
+falls back to a CPU implementation: if the library is missing, or there is no
+gfx950 device, construction of :class:`Ibl` raises.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libibl_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "ibl_hip.h")
+
+LUT_JITTER_COUNTER = 1
+LUT_JITTER_MIDPOINT = 2
+
+_u32 = ctypes.c_uint32
+_u64 = ctypes.c_uint64
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+
+_SIGNATURES = {
+    "ibl_init": ([_int], _int),
+    "ibl_shutdown": ([], _int),
+    "ibl_last_error": ([], ctypes.c_char_p),
+    "ibl_device_count": ([], _int),
+    "ibl_ggx_mip_levels": ([_u32, _u32, _u32], _u32),
+    "ibl_ggx_level_params": ([_u32, _u32, _u32, _u32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                              ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_u32)], _int),
+    "ibl_lambertian_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_ggx_level_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_brdf_lut_dev": ([_u32, _u32, _u32, _u64, _int, _u32, _u32, _vp, _vp], _int),
+    "ibl_rgbe_decode_dev": ([_vp, _vp, _u32, _vp], _int),
+    "ibl_rgbe_encode_dev": ([_vp, _vp, _u32, _vp], _int),
+    "ibl_downscale_dev": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_lambertian": ([_vp, _u32, _u32, _u32, _vp], _int),
+    "ibl_ggx_level": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp], _int),
+    "ibl_brdf_lut": ([_u32, _u32, _u32, _u64, _int, _vp], _int),
+    "ibl_rgbe_decode": ([_vp, _vp, _u32], _int),
+    "ibl_rgbe_encode": ([_vp, _vp, _u32], _int),
+    "ibl_downscale": ([_vp, _u32, _u32, _u32, _vp], _int),
+    "ibl_bake_rgbe": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_set_timing": ([_int], _int),
+    "ibl_last_kernel_ms": ([ctypes.POINTER(ctypes.c_float)], _int),
+    "ibl_set_counting": ([_int], _int),
+    "ibl_last_counts": ([ctypes.POINTER(_u64)] * 3, _int),
+}
+
+
+class IblError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("ibl error %d: %s" % (code, message))
+        self.code = code
+
+
+def build():
+    """Compile libibl_hip.so for gfx950 with hipcc (works without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+
+
+def exported_symbols():
+    """Names of the functions declared in include/ibl_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ibl_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the library and attach the prototypes.  torch is imported first so
+    that both share one HIP runtime (torch ships its own libamdhip64.so.7 and a
+    process must not hold two)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IblError(2, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    return _vp(t.data_ptr())
+
+
+class Ibl:
+    """One GPU's view of the library.  Device methods take and return torch CUDA
+    tensors shaped (6, H, W, 4); host methods take numpy arrays."""
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.lib.ibl_device_count() == 0:
+            raise IblError(2, "no HIP device visible; the IBL library has no CPU path")
+        torch.cuda.set_device(device)
+        self.device = torch.device("cuda", device)
+        self._check(self.lib.ibl_init(device))
+
+    # -- plumbing -----------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise IblError(rc, self.lib.ibl_last_error().decode())
+
+    def _stream(self, stream):
+        if stream is None:
+            stream = self.torch.cuda.current_stream(self.device)
+        return _vp(stream.cuda_stream)
+
+    def _env(self, env):
+        t = self.torch
+        assert env.is_cuda and env.dtype == t.float32 and env.is_contiguous(), "env must be a contiguous CUDA float32 tensor"
+        assert env.dim() == 4 and env.shape[0] == 6 and env.shape[3] == 4, tuple(env.shape)
+        return int(env.shape[2]), int(env.shape[1])
+
+    def close(self):
+        self.lib.ibl_shutdown()
+
+    # -- geometry ---------------------------------------------------------------------
+    def ggx_mip_levels(self, top_w, top_h, min_size):
+        return int(self.lib.ibl_ggx_mip_levels(top_w, top_h, min_size))
+
+    def ggx_level_params(self, mip, mips, in_w, in_h):
+        r, a2, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        ps = _u32()
+        self._check(self.lib.ibl_ggx_level_params(mip, mips, in_w, in_h, ctypes.byref(r), ctypes.byref(a2),
+                                                  ctypes.byref(c), ctypes.byref(ps)))
+        return dict(roughness=r.value, alpha2=a2.value, cutoff=c.value, patch=ps.value)
+
+    # -- device-resident entry points ------------------------------------------------
+    def lambertian(self, env, out_size, out_begin=0, out_count=None, out=None, stream=None):
+        w, h = self._env(env)
+        n_out = 6 * out_size * out_size
+        if out_count is None:
+            out_count = n_out - out_begin
+        if out is None:
+            out = self.torch.zeros((6, out_size, out_size, 4), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.ibl_lambertian_dev(_ptr(env), w, h, out_size, out_begin, out_count, _ptr(out),
+                                                self._stream(stream)))
+        return out
+
+    def ggx_level(self, env, out_w, mip, mips, out_begin=0, out_count=None, out=None, stream=None, out_h=None):
+        w, h = self._env(env)
+        out_h = out_w if out_h is None else out_h
+        n_out = 6 * out_w * out_h
+        if out_count is None:
+            out_count = n_out - out_begin
+        if out is None:
+            out = self.torch.zeros((6, out_h, out_w, 4), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.ibl_ggx_level_dev(_ptr(env), w, h, out_w, out_h, mip, mips, out_begin, out_count,
+                                               _ptr(out), self._stream(stream)))
+        return out
+
+    def brdf_lut(self, n_rough=256, n_cos=256, samples_sqrt=32, seed=0, mode=LUT_JITTER_COUNTER,
+                 cell_begin=0, cell_count=None, out=None, stream=None):
+        n = n_rough * n_cos
+        if cell_count is None:
+            cell_count = n - cell_begin
+        if out is None:
+            out = self.torch.zeros((n_rough, n_cos, 2), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.ibl_brdf_lut_dev(n_rough, n_cos, samples_sqrt, seed, mode, cell_begin, cell_count,
+                                              _ptr(out), self._stream(stream)))
+        return out
+
+    def rgbe_decode(self, rgbe, stream=None):
+        t = self.torch
+        assert rgbe.is_cuda and rgbe.dtype == t.uint8 and rgbe.is_contiguous() and rgbe.shape[-1] == 4
+        out = t.empty(tuple(rgbe.shape), dtype=t.float32, device=self.device)
+        self._check(self.lib.ibl_rgbe_decode_dev(_ptr(rgbe), _ptr(out), rgbe.numel() // 4, self._stream(stream)))
+        return out
+
+    def rgbe_encode(self, rgba, stream=None):
+        t = self.torch
+        assert rgba.is_cuda and rgba.dtype == t.float32 and rgba.is_contiguous() and rgba.shape[-1] == 4
+        out = t.empty(tuple(rgba.shape), dtype=t.uint8, device=self.device)
+        self._check(self.lib.ibl_rgbe_encode_dev(_ptr(rgba), _ptr(out), rgba.numel() // 4, self._stream(stream)))
+        return out
+
+    def downscale(self, env, d, stream=None):
+        w, h = self._env(env)
+        out = self.torch.empty((6, max(h // max(d, 1), 1), max(w // max(d, 1), 1), 4), dtype=self.torch.float32,
+                               device=self.device)
+        self._check(self.lib.ibl_downscale_dev(_ptr(env), w, h, d, _ptr(out), self._stream(stream)))
+        return out
+
+    # -- measurement --------------------------------------------------------------------
+    def set_timing(self, on):
+        self._check(self.lib.ibl_set_timing(int(bool(on))))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self._check(self.lib.ibl_last_kernel_ms(ctypes.byref(ms)))
+        return ms.value
+
+    def set_counting(self, on):
+        self._check(self.lib.ibl_set_counting(int(bool(on))))
+
+    def last_counts(self):
+        a, b, c = _u64(), _u64(), _u64()
+        self._check(self.lib.ibl_last_counts(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return dict(patch_tests=a.value, tested=b.value, accepted=c.value)
+
+    # -- host-buffer entry points ---------------------------------------------------------
+    @staticmethod
+    def _np_env(env):
+        env = np.ascontiguousarray(env, dtype=np.float32)
+        assert env.ndim == 4 and env.shape[0] == 6 and env.shape[3] == 4, env.shape
+        return env
+
+    def lambertian_host(self, env, out_size):
+        env = self._np_env(env)
+        out = np.zeros((6, out_size, out_size, 4), np.float32)
+        self._check(self.lib.ibl_lambertian(env.ctypes.data, env.shape[2], env.shape[1], out_size, out.ctypes.data))
+        return out
+
+    def ggx_level_host(self, env, out_w, mip, mips):
+        env = self._np_env(env)
+        out = np.zeros((6, out_w, out_w, 4), np.float32)
+        self._check(self.lib.ibl_ggx_level(env.ctypes.data, env.shape[2], env.shape[1], out_w, out_w, mip, mips,
+                                           out.ctypes.data))
+        return out
+
+    def brdf_lut_host(self, n_rough=256, n_cos=256, samples_sqrt=32, seed=0, mode=LUT_JITTER_COUNTER):
+        out = np.zeros((n_rough, n_cos, 2), np.float32)
+        self._check(self.lib.ibl_brdf_lut(n_rough, n_cos, samples_sqrt, seed, mode, out.ctypes.data))
+        return out
+
+    def rgbe_decode_host(self, rgbe):
+        rgbe = np.ascontiguousarray(rgbe, dtype=np.uint8)
+        out = np.zeros(rgbe.shape, np.float32)
+        self._check(self.lib.ibl_rgbe_decode(rgbe.ctypes.data, out.ctypes.data, rgbe.size // 4))
+        return out
+
+    def rgbe_encode_host(self, rgba):
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        out = np.zeros(rgba.shape, np.uint8)
+        self._check(self.lib.ibl_rgbe_encode(rgba.ctypes.data, out.ctypes.data, rgba.size // 4))
+        return out
+
+    def downscale_host(self, env, d):
+        env = self._np_env(env)
+        out = np.zeros((6, env.shape[1] // d, env.shape[2] // d, 4), np.float32)
+        self._check(self.lib.ibl_downscale(env.ctypes.data, env.shape[2], env.shape[1], d, out.ctypes.data))
+        return out
+
+    def bake_rgbe(self, rgbe, input_downscale=1, cubemap_size=16, lambertian=True, ggx=True):
+        """rgbe: (6*W, W, 4) uint8 strip.  Returns (lambertian strip or None, [ggx level strips])."""
+        rgbe = np.ascontiguousarray(rgbe, dtype=np.uint8)
+        w = rgbe.shape[1]
+        assert rgbe.shape == (6 * w, w, 4), rgbe.shape
+        lam = np.zeros((6 * cubemap_size, cubemap_size, 4), np.uint8) if lambertian else None
+        mips = self.ggx_mip_levels(w, w, cubemap_size) if ggx else 0
+        sizes = [w >> m for m in range(1, mips + 1)]
+        total = sum(6 * s * s * 4 for s in sizes)
+        gbuf = np.zeros(max(total, 1), np.uint8) if ggx else None
+        self._check(self.lib.ibl_bake_rgbe(rgbe.ctypes.data, w, input_downscale, cubemap_size,
+                                           lam.ctypes.data if lambertian else None,
+                                           gbuf.ctypes.data if ggx else None))
+        levels, off = [], 0
+        for s in sizes:
+            n = 6 * s * s * 4
+            levels.append(gbuf[off:off + n].reshape(6 * s, s, 4))
+            off += n
+        return lam, levels

@@ -1,0 +1,453 @@
+// C ABI of the IBL precompute library (declared in include/ibl_hip.h).
+// Host-side only: argument checking, the per-device workspace, stream and event
+// plumbing.  There is no CPU implementation behind any entry point: without a
+// gfx950 device ibl_init fails and every other call returns IBL_ENODEV.
+#include "ibl_hip.h"
+#include "ibl_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(IBL_EHIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+struct Buffer {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct State {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false, counting = false, timed_valid = false;
+    Buffer a, b, pn, partial, counts, stage_in, stage_out;
+    uint64_t last_counts[3] = {0, 0, 0};
+    bool counts_pending = false;
+} g;
+
+// Grow-only device allocation.  The old block is freed only after the device has
+// drained, because a previous asynchronous call may still be using it.
+int ensure(Buffer& buf, size_t bytes) {
+    if (bytes <= buf.cap) return IBL_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (buf.ptr) HIP_TRY(hipFree(buf.ptr));
+    buf.ptr = nullptr;
+    buf.cap = 0;
+    size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&buf.ptr, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(IBL_ENOMEM, "hipMalloc(%zu bytes): %s", want, hipGetErrorString(e));
+    }
+    buf.cap = want;
+    return IBL_OK;
+}
+
+void release(Buffer& buf) {
+    if (buf.ptr) (void)hipFree(buf.ptr);
+    buf.ptr = nullptr;
+    buf.cap = 0;
+}
+
+int check_ready() {
+    if (!g.ready) return fail(IBL_ENODEV, "ibl_init has not succeeded in this process");
+    return IBL_OK;
+}
+
+hipStream_t pick(void* stream) { return stream ? (hipStream_t)stream : g.stream; }
+
+bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+int check_cube(uint32_t w, uint32_t h, const char* what) {
+    if (w == 0 || h == 0) return fail(IBL_EINVAL, "%s: empty cube face %ux%u", what, w, h);
+    if (w != h) return fail(IBL_EINVAL, "%s: cube faces must be square, got %ux%u", what, w, h);
+    if ((uint64_t)w * h * 6 > 0x7fffffffull / 4) return fail(IBL_EINVAL, "%s: cube %ux%u too large", what, w, h);
+    return IBL_OK;
+}
+
+int check_range(uint32_t begin, uint32_t count, uint64_t total, const char* what) {
+    if (begin > total || count > total - begin)
+        return fail(IBL_EINVAL, "%s: range [%u, %u+%u) exceeds %llu", what, begin, begin, count,
+                    (unsigned long long)total);
+    return IBL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ibl_last_error(void) { return g_err; }
+
+int ibl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int ibl_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return fail(IBL_ENODEV, "no HIP device visible (%s); this library has no CPU path",
+                    e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    }
+    if (g.ready) {
+        if (device < 0 || device == g.device) return IBL_OK;
+        ibl_shutdown();
+    }
+    if (device >= n) return fail(IBL_EINVAL, "device %d out of range (have %d)", device, n);
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&g.ev0));
+    HIP_TRY(hipEventCreate(&g.ev1));
+    g.device = device;
+    g.ready = true;
+    return IBL_OK;
+}
+
+int ibl_shutdown(void) {
+    if (!g.ready) return IBL_OK;
+    (void)hipSetDevice(g.device);
+    (void)hipDeviceSynchronize();
+    release(g.a); release(g.b); release(g.pn); release(g.partial); release(g.counts);
+    release(g.stage_in); release(g.stage_out);
+    if (g.ev0) (void)hipEventDestroy(g.ev0);
+    if (g.ev1) (void)hipEventDestroy(g.ev1);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    g = State();
+    return IBL_OK;
+}
+
+uint32_t ibl_ggx_mip_levels(uint32_t top_w, uint32_t top_h, uint32_t min_size) {
+    if (top_w == 0 || top_h == 0 || min_size == 0) return 0;
+    uint32_t m = top_w > top_h ? top_w : top_h;
+    if (m < min_size) return 0;
+    return ibl::ggx_mip_levels(top_w, top_h, min_size);
+}
+
+int ibl_ggx_level_params(uint32_t mip_level, uint32_t mip_levels, uint32_t in_w, uint32_t in_h,
+                         float* roughness, float* alpha2, float* cutoff, uint32_t* patch_size) {
+    if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
+        return fail(IBL_EINVAL, "ggx level %u of %u is out of range", mip_level, mip_levels);
+    ibl::GgxLevel lv = ibl::ggx_level_params(mip_level, mip_levels, in_w, in_h);
+    if (roughness) *roughness = lv.roughness;
+    if (alpha2) *alpha2 = lv.alpha2;
+    if (cutoff) *cutoff = lv.cutoff;
+    if (patch_size) *patch_size = lv.patch;
+    return IBL_OK;
+}
+
+int ibl_set_timing(int enabled) { g.timing = enabled != 0; g.timed_valid = false; return IBL_OK; }
+int ibl_set_counting(int enabled) { g.counting = enabled != 0; return IBL_OK; }
+
+int ibl_last_kernel_ms(float* ms) {
+    if (int rc = check_ready()) return rc;
+    if (!ms) return fail(IBL_EINVAL, "ms is null");
+    if (!g.timed_valid) return fail(IBL_EINVAL, "no timed kernel: call ibl_set_timing(1) before a *_dev call");
+    HIP_TRY(hipEventSynchronize(g.ev1));
+    HIP_TRY(hipEventElapsedTime(ms, g.ev0, g.ev1));
+    return IBL_OK;
+}
+
+int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
+    if (int rc = check_ready()) return rc;
+    if (g.counts_pending) {
+        unsigned long long h[3];
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h, g.counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
+        g.last_counts[1] = h[1];
+        g.last_counts[2] = h[2];
+        g.counts_pending = false;
+    }
+    if (patch_tests) *patch_tests = g.last_counts[0];
+    if (tested) *tested = g.last_counts[1];
+    if (accepted) *accepted = g.last_counts[2];
+    return IBL_OK;
+}
+
+// ---- device-resident entry points ---------------------------------------------
+
+int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
+                       uint32_t out_begin, uint32_t out_count, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_env || !d_out) return fail(IBL_EINVAL, "lambertian: null pointer");
+    if (int rc = check_cube(in_w, in_h, "lambertian input")) return rc;
+    if (int rc = check_cube(out_size, out_size, "lambertian output")) return rc;
+    const uint64_t n_out = (uint64_t)out_size * out_size * 6;
+    if (int rc = check_range(out_begin, out_count, n_out, "lambertian")) return rc;
+    const uint32_t n_in = in_w * in_h * 6;
+    g.last_counts[0] = 0;
+    g.last_counts[1] = (uint64_t)out_count * n_in;
+    g.last_counts[2] = 0;
+    g.counts_pending = false;
+    if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
+    ibl::LambertianPlan pl = ibl::lambertian_plan(n_in, out_count);
+    if (int rc = ensure(g.a, pl.prep_bytes_a)) return rc;
+    if (int rc = ensure(g.b, pl.prep_bytes_b)) return rc;
+    if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
+    hipStream_t s = pick(stream);
+    HIP_TRY(ibl::lambertian_launch(pl, d_env, in_w, in_h, out_size, out_begin, out_count, d_out, g.a.ptr, g.b.ptr,
+                                   (double*)g.partial.ptr, s, g.timing ? g.ev0 : nullptr, g.timing ? g.ev1 : nullptr));
+    g.timed_valid = g.timing;
+    return IBL_OK;
+}
+
+int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                      uint32_t mip_level, uint32_t mip_levels,
+                      uint32_t out_begin, uint32_t out_count, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_env || !d_out) return fail(IBL_EINVAL, "ggx: null pointer");
+    if (int rc = check_cube(in_w, in_h, "ggx input")) return rc;
+    if (int rc = check_cube(out_w, out_h, "ggx output")) return rc;
+    if (in_w < 16)
+        return fail(IBL_EINVAL, "ggx: input faces must be at least 16x16 (patch size would be 0), got %u", in_w);
+    if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
+        return fail(IBL_EINVAL, "ggx: level %u of %u is out of range", mip_level, mip_levels);
+    const uint64_t n_out = (uint64_t)out_w * out_h * 6;
+    if (int rc = check_range(out_begin, out_count, n_out, "ggx")) return rc;
+    ibl::GgxPlan pl = ibl::ggx_plan(in_w, in_h, out_w, out_h, mip_level, mip_levels, out_count);
+    if (in_w % pl.lv.patch != 0)
+        return fail(IBL_EINVAL, "ggx: input width %u is not a multiple of its patch size %u", in_w, pl.lv.patch);
+    g.last_counts[0] = (uint64_t)out_count * pl.n_patches;
+    g.last_counts[1] = g.last_counts[2] = 0;
+    g.counts_pending = false;
+    if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
+    if (int rc = ensure(g.a, pl.prep_bytes_a)) return rc;
+    if (int rc = ensure(g.b, pl.prep_bytes_b)) return rc;
+    if (int rc = ensure(g.pn, pl.prep_bytes_pn)) return rc;
+    if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
+    hipStream_t s = pick(stream);
+    unsigned long long* d_counts = nullptr;
+    if (g.counting) {
+        if (int rc = ensure(g.counts, 4 * sizeof(unsigned long long))) return rc;
+        d_counts = (unsigned long long*)g.counts.ptr;
+        HIP_TRY(hipMemsetAsync(d_counts, 0, 4 * sizeof(unsigned long long), s));
+    }
+    HIP_TRY(ibl::ggx_launch(pl, d_env, in_w, in_h, out_w, out_h, out_begin, out_count, d_out, g.a.ptr, g.b.ptr,
+                            g.pn.ptr, (double*)g.partial.ptr, d_counts, s, g.timing ? g.ev0 : nullptr,
+                            g.timing ? g.ev1 : nullptr));
+    g.timed_valid = g.timing;
+    g.counts_pending = g.counting;
+    return IBL_OK;
+}
+
+int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
+                     uint32_t cell_begin, uint32_t cell_count, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_out) return fail(IBL_EINVAL, "brdf_lut: null pointer");
+    if (n_rough == 0 || n_cos == 0 || (uint64_t)n_rough * n_cos > (1u << 26))
+        return fail(IBL_EINVAL, "brdf_lut: table %ux%u out of range", n_rough, n_cos);
+    if (samples_sqrt == 0 || samples_sqrt > 65535) return fail(IBL_EINVAL, "brdf_lut: samples_sqrt %u out of range", samples_sqrt);
+    if (jitter_mode != IBL_LUT_JITTER_COUNTER && jitter_mode != IBL_LUT_JITTER_MIDPOINT)
+        return fail(IBL_EINVAL, "brdf_lut: unknown jitter mode %d", jitter_mode);
+    if (int rc = check_range(cell_begin, cell_count, (uint64_t)n_rough * n_cos, "brdf_lut")) return rc;
+    g.last_counts[0] = 0;
+    g.last_counts[1] = (uint64_t)cell_count * samples_sqrt * samples_sqrt;
+    g.last_counts[2] = 0;
+    g.counts_pending = false;
+    hipStream_t s = pick(stream);
+    HIP_TRY(ibl::brdf_lut_launch(n_rough, n_cos, samples_sqrt, seed, jitter_mode, cell_begin, cell_count, d_out, s,
+                                 g.timing ? g.ev0 : nullptr, g.timing ? g.ev1 : nullptr));
+    g.timed_valid = g.timing;
+    return IBL_OK;
+}
+
+int ibl_rgbe_decode_dev(const uint8_t* d_rgbe, float* d_rgba, uint32_t n, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (n && (!d_rgbe || !d_rgba)) return fail(IBL_EINVAL, "rgbe_decode: null pointer");
+    HIP_TRY(ibl::rgbe_decode_launch(d_rgbe, d_rgba, n, pick(stream)));
+    return IBL_OK;
+}
+
+int ibl_rgbe_encode_dev(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (n && (!d_rgba || !d_rgbe)) return fail(IBL_EINVAL, "rgbe_encode: null pointer");
+    HIP_TRY(ibl::rgbe_encode_launch(d_rgba, d_rgbe, n, pick(stream)));
+    return IBL_OK;
+}
+
+int ibl_downscale_dev(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_env || !d_out) return fail(IBL_EINVAL, "downscale: null pointer");
+    if (int rc = check_cube(w, h, "downscale input")) return rc;
+    // cube.cpp:433-435
+    if (!is_pow2(d)) return fail(IBL_EINVAL, "scale factor for --input-downscale should be a power of 2 >= 1");
+    if (d > w || w % d != 0) return fail(IBL_EINVAL, "downscale: factor %u does not divide the face width %u", d, w);
+    HIP_TRY(ibl::downscale_launch(d_env, w, h, d, d_out, pick(stream)));
+    return IBL_OK;
+}
+
+// ---- host-buffer entry points ---------------------------------------------------
+
+namespace {
+
+// Copies `bytes` from the host into the staging-in buffer.
+int stage_in(const void* host, size_t bytes) {
+    if (int rc = ensure(g.stage_in, bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(g.stage_in.ptr, host, bytes, hipMemcpyHostToDevice, g.stream));
+    return IBL_OK;
+}
+
+int stage_out(void* host, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(host, g.stage_out.ptr, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return IBL_OK;
+}
+
+}  // namespace
+
+int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* out) {
+    if (int rc = check_ready()) return rc;
+    if (!env || !out) return fail(IBL_EINVAL, "lambertian: null pointer");
+    if (int rc = check_cube(in_w, in_h, "lambertian input")) return rc;
+    if (int rc = check_cube(out_size, out_size, "lambertian output")) return rc;
+    const size_t in_bytes = (size_t)in_w * in_h * 6 * 16, out_bytes = (size_t)out_size * out_size * 6 * 16;
+    if (int rc = stage_in(env, in_bytes)) return rc;
+    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
+    if (int rc = ibl_lambertian_dev((const float*)g.stage_in.ptr, in_w, in_h, out_size, 0, out_size * out_size * 6,
+                                    (float*)g.stage_out.ptr, nullptr)) return rc;
+    return stage_out(out, out_bytes);
+}
+
+int ibl_ggx_level(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                  uint32_t mip_level, uint32_t mip_levels, float* out) {
+    if (int rc = check_ready()) return rc;
+    if (!env || !out) return fail(IBL_EINVAL, "ggx: null pointer");
+    if (int rc = check_cube(in_w, in_h, "ggx input")) return rc;
+    if (int rc = check_cube(out_w, out_h, "ggx output")) return rc;
+    const size_t in_bytes = (size_t)in_w * in_h * 6 * 16, out_bytes = (size_t)out_w * out_h * 6 * 16;
+    if (int rc = stage_in(env, in_bytes)) return rc;
+    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
+    if (int rc = ibl_ggx_level_dev((const float*)g.stage_in.ptr, in_w, in_h, out_w, out_h, mip_level, mip_levels, 0,
+                                   out_w * out_h * 6, (float*)g.stage_out.ptr, nullptr)) return rc;
+    return stage_out(out, out_bytes);
+}
+
+int ibl_brdf_lut(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
+                 float* out_slope_bias) {
+    if (int rc = check_ready()) return rc;
+    if (!out_slope_bias) return fail(IBL_EINVAL, "brdf_lut: null pointer");
+    if (n_rough == 0 || n_cos == 0 || (uint64_t)n_rough * n_cos > (1u << 26))
+        return fail(IBL_EINVAL, "brdf_lut: table %ux%u out of range", n_rough, n_cos);
+    const size_t out_bytes = (size_t)n_rough * n_cos * 2 * sizeof(float);
+    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
+    if (int rc = ibl_brdf_lut_dev(n_rough, n_cos, samples_sqrt, seed, jitter_mode, 0, n_rough * n_cos,
+                                  (float*)g.stage_out.ptr, nullptr)) return rc;
+    return stage_out(out_slope_bias, out_bytes);
+}
+
+int ibl_rgbe_decode(const uint8_t* rgbe, float* rgba, uint32_t n) {
+    if (int rc = check_ready()) return rc;
+    if (n == 0) return IBL_OK;
+    if (!rgbe || !rgba) return fail(IBL_EINVAL, "rgbe_decode: null pointer");
+    if (int rc = stage_in(rgbe, (size_t)n * 4)) return rc;
+    if (int rc = ensure(g.stage_out, (size_t)n * 16)) return rc;
+    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)g.stage_in.ptr, (float*)g.stage_out.ptr, n, nullptr)) return rc;
+    return stage_out(rgba, (size_t)n * 16);
+}
+
+int ibl_rgbe_encode(const float* rgba, uint8_t* rgbe, uint32_t n) {
+    if (int rc = check_ready()) return rc;
+    if (n == 0) return IBL_OK;
+    if (!rgba || !rgbe) return fail(IBL_EINVAL, "rgbe_encode: null pointer");
+    if (int rc = stage_in(rgba, (size_t)n * 16)) return rc;
+    if (int rc = ensure(g.stage_out, (size_t)n * 4)) return rc;
+    if (int rc = ibl_rgbe_encode_dev((const float*)g.stage_in.ptr, (uint8_t*)g.stage_out.ptr, n, nullptr)) return rc;
+    return stage_out(rgbe, (size_t)n * 4);
+}
+
+int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* out) {
+    if (int rc = check_ready()) return rc;
+    if (!env || !out) return fail(IBL_EINVAL, "downscale: null pointer");
+    if (int rc = check_cube(w, h, "downscale input")) return rc;
+    if (!is_pow2(d) || d > w || w % d != 0) return fail(IBL_EINVAL, "scale factor for --input-downscale should be a power of 2 >= 1");
+    const size_t in_bytes = (size_t)w * h * 6 * 16, out_bytes = (size_t)(w / d) * (h / d) * 6 * 16;
+    if (int rc = stage_in(env, in_bytes)) return rc;
+    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
+    if (int rc = ibl_downscale_dev((const float*)g.stage_in.ptr, w, h, d, (float*)g.stage_out.ptr, nullptr)) return rc;
+    return stage_out(out, out_bytes);
+}
+
+int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
+                  uint8_t* lambertian_out, uint8_t* ggx_out) {
+    if (int rc = check_ready()) return rc;
+    if (!rgbe_in) return fail(IBL_EINVAL, "bake: null input");
+    if (int rc = check_cube(w, w, "bake input")) return rc;
+    if (!is_pow2(input_downscale))
+        return fail(IBL_EINVAL, "scale factor for --input-downscale should be a power of 2 >= 1");
+    if (input_downscale > w || w % input_downscale != 0)
+        return fail(IBL_EINVAL, "bake: downscale %u does not divide the face width %u", input_downscale, w);
+    if (cubemap_size == 0) return fail(IBL_EINVAL, "bake: cubemap size 0");
+    const uint32_t n_full = w * w * 6;
+    const uint32_t dw = w / input_downscale;
+    const uint32_t n_ds = dw * dw * 6;
+    const uint32_t n_lamb = cubemap_size * cubemap_size * 6;
+    // Device layout of the staging-in block: [rgbe bytes][full float cube][downscaled float cube]
+    const size_t off_full = ((size_t)n_full * 4 + 255) & ~(size_t)255;
+    const size_t off_ds = off_full + (size_t)n_full * 16;
+    const size_t in_total = off_ds + (input_downscale > 1 ? (size_t)n_ds * 16 : 0);
+    if (int rc = ensure(g.stage_in, in_total)) return rc;
+    char* base = (char*)g.stage_in.ptr;
+    HIP_TRY(hipMemcpyAsync(base, rgbe_in, (size_t)n_full * 4, hipMemcpyHostToDevice, g.stream));
+    float* d_full = (float*)(base + off_full);
+    float* d_env = d_full;
+    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)base, d_full, n_full, nullptr)) return rc;
+    if (input_downscale > 1) {
+        d_env = (float*)(base + off_ds);
+        if (int rc = ibl_downscale_dev(d_full, w, w, input_downscale, d_env, nullptr)) return rc;
+    }
+    // Staging-out block: [float scratch of the largest output][rgbe bytes]
+    uint32_t mips = ggx_out ? ibl_ggx_mip_levels(w, w, cubemap_size) : 0;
+    uint32_t n_max = lambertian_out ? n_lamb : 0;
+    if (mips) { uint32_t n1 = (w / 2) * (w / 2) * 6; if (n1 > n_max) n_max = n1; }
+    if (n_max == 0) { HIP_TRY(hipStreamSynchronize(g.stream)); return IBL_OK; }
+    const size_t off_bytes = (size_t)n_max * 16;
+    if (int rc = ensure(g.stage_out, off_bytes + (size_t)n_max * 4)) return rc;
+    float* d_f = (float*)g.stage_out.ptr;
+    uint8_t* d_e = (uint8_t*)g.stage_out.ptr + off_bytes;
+    if (lambertian_out) {
+        if (int rc = ibl_lambertian_dev(d_env, dw, dw, cubemap_size, 0, n_lamb, d_f, nullptr)) return rc;
+        if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n_lamb, nullptr)) return rc;
+        HIP_TRY(hipMemcpyAsync(lambertian_out, d_e, (size_t)n_lamb * 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+    }
+    size_t out_off = 0;
+    uint32_t mw = w / 2;
+    for (uint32_t m = 1; m <= mips; m++, mw /= 2) {
+        const uint32_t n_m = mw * mw * 6;
+        if (int rc = ibl_ggx_level_dev(d_env, dw, dw, mw, mw, m, mips, 0, n_m, d_f, nullptr)) return rc;
+        if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n_m, nullptr)) return rc;
+        HIP_TRY(hipMemcpyAsync(ggx_out + out_off, d_e, (size_t)n_m * 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        out_off += (size_t)n_m * 4;
+    }
+    return IBL_OK;
+}
+
+}  // extern "C"

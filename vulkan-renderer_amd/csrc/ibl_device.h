@@ -1,0 +1,85 @@
+// Device-side helpers shared by the IBL kernels (gfx950 only).
+//
+// Two kinds of arithmetic live here:
+//  * "ref_*" functions reproduce the reference's float32 operation order without
+//    fused multiply-add (the reference is built for baseline x86-64, which has
+//    none); they are used wherever a yes/no decision or a stored direction must
+//    agree bit for bit with the CPU tool (texel directions, patch cull test).
+//  * everything else is free to fuse and reorder: the sums they feed are checked
+//    against the reference by tolerance, not bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct F3 { float x, y, z; };
+
+// getNormalFrom, src/utilities/cube.cpp:31-50.  s and t are evaluated in double
+// and rounded once.
+__device__ __forceinline__ F3 ref_normal_from(uint32_t face, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
+#pragma clang fp contract(off)
+    float s = (float)((((double)(float)x + 0.5) / (double)(float)w) * 2.0 - 1.0);
+    float t = (float)((((double)(float)y + 0.5) / (double)(float)h) * 2.0 - 1.0);
+    F3 r;
+    switch (face) {
+        case 0: r.x = 1.0f;  r.y = -t;    r.z = -s;   break;
+        case 1: r.x = -1.0f; r.y = -t;    r.z = s;    break;
+        case 2: r.x = s;     r.y = 1.0f;  r.z = t;    break;
+        case 3: r.x = s;     r.y = -1.0f; r.z = -t;   break;
+        case 4: r.x = s;     r.y = -t;    r.z = 1.0f; break;
+        default: r.x = -s;   r.y = -t;    r.z = -1.0f; break;
+    }
+    return r;
+}
+
+// linear::dot, include/linear.hpp:100-107: left-to-right, no contraction.
+__device__ __forceinline__ float ref_dot(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    float r = a.x * b.x;
+    r = r + a.y * b.y;
+    r = r + a.z * b.z;
+    return r;
+}
+
+// linear::normalize, include/linear.hpp:93-95,114-122: (1/sqrt(v.v)) * v with a
+// correctly rounded square root and division.
+__device__ __forceinline__ F3 ref_normalize(F3 v) {
+#pragma clang fp contract(off)
+    float inv = __fdiv_rn(1.0f, __fsqrt_rn(ref_dot(v, v)));
+    F3 r = { inv * v.x, inv * v.y, inv * v.z };
+    return r;
+}
+
+__device__ __forceinline__ F3 ref_add(F3 a, F3 b) {
+    F3 r = { a.x + b.x, a.y + b.y, a.z + b.z };
+    return r;
+}
+
+// The cull test of cube.cpp:256-258 (patch) and the first half of :267-271
+// (texel): cosHalf^2 > cutoff * |half|^2 with half = u + n.
+__device__ __forceinline__ bool ref_cone_test(F3 u, F3 n, float cutoff) {
+#pragma clang fp contract(off)
+    F3 half = ref_add(u, n);
+    float ch = ref_dot(half, n);
+    float lhs = ch * ch;
+    float rhs = cutoff * ref_dot(half, half);
+    return lhs > rhs;
+}
+
+// Output texel index (face, y, x order) -> unit direction, cube.cpp:97,242.
+__device__ __forceinline__ F3 ref_out_normal(uint32_t o, uint32_t w, uint32_t h) {
+    uint32_t f = o / (w * h);
+    uint32_t rem = o - f * (w * h);
+    uint32_t y = rem / w;
+    uint32_t x = rem - y * w;
+    return ref_normalize(ref_normal_from(f, x, y, w, h));
+}
+
+// v_fma_f32 with the clamp output modifier: max(0, min(1, a*b+c)) in one VALU
+// issue.  Every dot product clamped this way in these kernels is between a unit
+// vector and a vector of length <= 1, so the upper bound never binds and this is
+// the max(0, .) of cube.cpp:112-115 for free.
+__device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}

@@ -1,0 +1,59 @@
+// Host-visible launch plans and launchers of the IBL kernels (internal to the
+// library; the public surface is include/ibl_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ibl {
+
+struct LambertianPlan {
+    int p;                 // output texels per thread
+    uint32_t slice_len;    // input texels per slice (multiple of the LDS tile)
+    uint32_t n_slices;
+    uint32_t out_blocks;
+    size_t partial_bytes;  // [slice][3][out_count] double
+    size_t prep_bytes_a;   // float4 per input texel
+    size_t prep_bytes_b;   // float2 per input texel
+};
+LambertianPlan lambertian_plan(uint32_t n_in, uint32_t out_count);
+hipError_t lambertian_launch(const LambertianPlan& pl, const float* d_env, uint32_t in_w, uint32_t in_h,
+                             uint32_t out_size, uint32_t out_begin, uint32_t out_count, float* d_out,
+                             void* d_a, void* d_b, double* d_partial, hipStream_t stream,
+                             hipEvent_t ev0, hipEvent_t ev1);
+
+struct GgxLevel {          // cube.cpp:161-175
+    float roughness, alpha2, cutoff;
+    uint32_t patch;        // patch edge in texels
+};
+GgxLevel ggx_level_params(uint32_t mip, uint32_t mips, uint32_t in_w, uint32_t in_h);
+uint32_t ggx_mip_levels(uint32_t top_w, uint32_t top_h, uint32_t min_size);
+
+struct GgxPlan {
+    GgxLevel lv;
+    int px, py;                    // output texels per thread = px*py; tile = 16px x 16py
+    uint32_t tiles_x, tiles_y;     // tiles per face
+    uint32_t n_patches;            // 6 * (w/patch) * (h/patch)
+    uint32_t patches_per_slice;
+    uint32_t n_slices;
+    size_t partial_bytes;          // [slice][out_count][4] double
+    size_t prep_bytes_a;           // float4 per input texel (unit direction, |w|^-3)
+    size_t prep_bytes_b;           // float4 per input texel (radiance * |w|^-3)
+    size_t prep_bytes_pn;          // float4 per patch (unit centre direction)
+};
+GgxPlan ggx_plan(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h, uint32_t mip, uint32_t mips,
+                 uint32_t out_count);
+hipError_t ggx_launch(const GgxPlan& pl, const float* d_env, uint32_t in_w, uint32_t in_h,
+                      uint32_t out_w, uint32_t out_h, uint32_t out_begin, uint32_t out_count, float* d_out,
+                      void* d_a, void* d_b, void* d_pn, double* d_partial, unsigned long long* d_counts,
+                      hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+
+hipError_t brdf_lut_launch(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int mode,
+                           uint32_t cell_begin, uint32_t cell_count, float* d_out, hipStream_t stream,
+                           hipEvent_t ev0, hipEvent_t ev1);
+
+hipError_t rgbe_decode_launch(const uint8_t* d_rgbe, float* d_rgba, uint32_t n, hipStream_t stream);
+hipError_t rgbe_encode_launch(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, hipStream_t stream);
+hipError_t downscale_launch(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, hipStream_t stream);
+
+}  // namespace ibl

@@ -1,0 +1,188 @@
+// Split-sum BRDF table, RGBE codec and box downscale for gfx950.
+//
+// brdf_lut_cells   generateGGXLUT's cell loop, src/utilities/cube.cpp:346-385.
+//     One 256-thread workgroup per (roughness, cos theta_v) cell; the
+//     samples_sqrt^2 strata are dealt round-robin to the threads, every thread
+//     keeps FP64 slope/bias sums, and the workgroup combines them with a
+//     fixed-shape wavefront butterfly + LDS tree, so a cell's value depends on
+//     (seed, cell, samples_sqrt) only.  The per-sample arithmetic keeps the
+//     reference's mix of float and double (angles and trig in double, BRDF terms
+//     in float).  The reference seeds std::mt19937 from std::random_device; here
+//     the jitter is a counter-based hash of (seed, cell, sample) or the stratum
+//     midpoint.
+// rgbe_decode / rgbe_encode   src/util.cpp:93-145, one texel per thread.
+// downscale_box    cube.cpp:482-501, one output texel per thread, float sums in
+//     (row, column) order.
+#include "ibl_device.h"
+#include "ibl_kernels.h"
+
+namespace ibl {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void brdf_lut_cells(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt,
+                                                       uint64_t seed, int mode, uint32_t cell_begin,
+                                                       float2* __restrict__ out) {
+#pragma clang fp contract(off)
+    __shared__ double s_slope[4], s_bias[4];
+    const uint32_t cell = cell_begin + blockIdx.x;
+    const uint32_t ri = cell / n_cos, ci = cell - ri * n_cos;
+    const float roughness = (float)(((double)(float)ri + 0.5) / (double)n_rough);
+    const float alpha = roughness * roughness;
+    const float a2 = alpha * alpha;
+    const float cos_v = (float)(((double)(float)ci + 0.5) / (double)n_cos);
+    const float vx = (float)sqrt(1.0 - (double)(cos_v * cos_v));
+    const float vz = cos_v;
+    const float k = alpha / 2;
+    const float g1v = vz / (vz * (1 - k) + k);
+    const double inv_s = 1.0 / (double)samples_sqrt;
+    const uint32_t n_samples = samples_sqrt * samples_sqrt;
+
+    double slope = 0.0, bias = 0.0;
+    for (uint32_t s = threadIdx.x; s < n_samples; s += blockDim.x) {
+        const uint32_t sx = s / samples_sqrt, sy = s - sx * samples_sqrt;
+        double j1, j2;
+        if (mode == 1) {
+            uint64_t h = mix64(seed + 0x9e3779b97f4a7c15ull * ((((uint64_t)cell) << 32 | (uint64_t)s) + 1ull));
+            j1 = (double)(uint32_t)(h & 0xffffffffu) * (1.0 / 4294967296.0) * inv_s;
+            j2 = (double)(uint32_t)(h >> 32) * (1.0 / 4294967296.0) * inv_s;
+        } else {
+            j1 = 0.5 * inv_s; j2 = 0.5 * inv_s;
+        }
+        const float ux = (float)((double)((float)sx / (float)samples_sqrt) + j1);
+        const float uy = (float)((double)((float)sy / (float)samples_sqrt) + j2);
+        const float phi = (float)(2 * 3.14159265358979323846 * (double)ux);
+        const float cos_t = (float)sqrt((1.0 - (double)uy) / (1.0 + ((double)a2 - 1.0) * (double)uy));
+        const float sin_t = (float)sqrt(1.0 - (double)(cos_t * cos_t));
+        double sphi, cphi;
+        sincos((double)phi, &sphi, &cphi);
+        const float hx = (float)((double)sin_t * cphi);
+        const float hy = (float)((double)sin_t * sphi);
+        const float hz = cos_t;
+        float vh = vx * hx;          // linear::dot with v.y == 0
+        vh = vh + 0.0f * hy;
+        vh = vh + vz * hz;
+        const float two_vh = 2.0f * vh;
+        const float lz = two_vh * hz - vz;
+        if (lz > 0.0f) {
+            const float g1l = lz / (lz * (1 - k) + k);
+            const float g = g1l * g1v;
+            const float fres = powf(1 - vh, 5.0f);
+            const float norm = vh / (hz * vz);
+            slope += (double)(g * (1 - fres) * norm);
+            bias += (double)(g * fres * norm);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        slope += __shfl_xor(slope, off);
+        bias += __shfl_xor(bias, off);
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_slope[wave] = slope; s_bias[wave] = bias; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = (s_slope[0] + s_slope[1]) + (s_slope[2] + s_slope[3]);
+        double b = (s_bias[0] + s_bias[1]) + (s_bias[2] + s_bias[3]);
+        s /= (double)n_samples;
+        b /= (double)n_samples;
+        out[cell] = make_float2((float)s, (float)b);
+    }
+}
+
+hipError_t brdf_lut_launch(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int mode,
+                           uint32_t cell_begin, uint32_t cell_count, float* d_out, hipStream_t stream,
+                           hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    if (cell_count)
+        brdf_lut_cells<<<cell_count, 256, 0, stream>>>(n_rough, n_cos, samples_sqrt, seed, mode, cell_begin,
+                                                       (float2*)d_out);
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    return hipGetLastError();
+}
+
+// ---- RGBE codec ---------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void rgbe_decode_k(const uchar4* __restrict__ src, float4* __restrict__ dst, uint32_t n) {
+#pragma clang fp contract(off)
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uchar4 s = src[i];
+    float4 d = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (!(s.x == 0 && s.y == 0 && s.z == 0 && s.w == 0)) {
+        int e = (int)s.w - 128;
+        d.x = ldexpf(((float)s.x + 0.5f) / 256.0f, e);
+        d.y = ldexpf(((float)s.y + 0.5f) / 256.0f, e);
+        d.z = ldexpf(((float)s.z + 0.5f) / 256.0f, e);
+    }
+    dst[i] = d;
+}
+
+__device__ __forceinline__ unsigned char clamp_byte(int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ __launch_bounds__(256) void rgbe_encode_k(const float4* __restrict__ src, uchar4* __restrict__ dst, uint32_t n) {
+#pragma clang fp contract(off)
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = src[i];
+    float m = (s.x < s.y) ? s.y : s.x;
+    m = (m < s.z) ? s.z : m;
+    uchar4 d;
+    if (m <= 1e-32f) {
+        d = make_uchar4(0, 0, 0, 0);
+    } else {
+        int e;
+        float frac_mult = __fdiv_rn(256.0f * frexpf(m, &e), m);
+        if (e > 127) {
+            d = make_uchar4(255, 255, 255, 255);
+        } else {
+            d.x = clamp_byte((int)(s.x * frac_mult));
+            d.y = clamp_byte((int)(s.y * frac_mult));
+            d.z = clamp_byte((int)(s.z * frac_mult));
+            d.w = (unsigned char)(e + 128);
+        }
+    }
+    dst[i] = d;
+}
+
+hipError_t rgbe_decode_launch(const uint8_t* d_rgbe, float* d_rgba, uint32_t n, hipStream_t stream) {
+    if (n) rgbe_decode_k<<<(n + 255) / 256, 256, 0, stream>>>((const uchar4*)d_rgbe, (float4*)d_rgba, n);
+    return hipGetLastError();
+}
+
+hipError_t rgbe_encode_launch(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, hipStream_t stream) {
+    if (n) rgbe_encode_k<<<(n + 255) / 256, 256, 0, stream>>>((const float4*)d_rgba, (uchar4*)d_rgbe, n);
+    return hipGetLastError();
+}
+
+// ---- box downscale --------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void downscale_box(const float4* __restrict__ env, uint32_t w, uint32_t ow,
+                                                      uint32_t n_out, uint32_t d, float4* __restrict__ out) {
+#pragma clang fp contract(off)
+    uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    uint32_t y = o / ow, x = o - y * ow;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for (uint32_t yy = 0; yy < d; yy++) {
+        const float4* row = env + (size_t)(y * d + yy) * w + (size_t)x * d;
+        for (uint32_t xx = 0; xx < d; xx++) {
+            float4 t = row[xx];
+            ax += t.x; ay += t.y; az += t.z;
+        }
+    }
+    const float inv = __fdiv_rn(1.0f, (float)(d * d));
+    out[o] = make_float4(inv * ax, inv * ay, inv * az, 0.0f);
+}
+
+hipError_t downscale_launch(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, hipStream_t stream) {
+    const uint32_t ow = w / d, oh = h / d;
+    const uint32_t n_out = ow * oh * 6;
+    if (n_out) downscale_box<<<(n_out + 255) / 256, 256, 0, stream>>>((const float4*)d_env, w, ow, n_out, d, (float4*)d_out);
+    return hipGetLastError();
+}
+
+}  // namespace ibl
