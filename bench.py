@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Benchmark of the IBL precompute hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c1|c2]
+
+A "step" is one pass of the hot path over one synthetic environment that is
+already resident in HBM.  The default workload is BASELINE config 4, the one
+the metric ("env-prefilter GSamples/s at 1/2/4/8 MI355X") is quoted on across
+1-8 GPUs: the brute-force Lambertian convolution of a 1024x1024/face environment
+into 128x128/face (6.18e11 (output, input) texel pairs).  With N > 1 (one process
+per GPU, launched by torch.distributed.run) the output texels are split into N
+contiguous ranges, every rank bakes its range against the full input, and one
+RCCL all-gather assembles the cube on every rank; total work is fixed, so the
+scaling is "strong".
+
+Rank 0 prints ONE JSON line.  `value` is samples of the whole job per second;
+`roofline` prices the dominant kernel's algorithmic FP32 work (flop per sample x
+samples per launch / that kernel's mean duration from HIP events on its own
+stream) against the 157.3 TFLOP/s FP32 vector peak; `cpu_baseline` is the CPU
+oracle (a port of the reference's loop, recomputing the input direction per pair
+as the reference does) timed on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3     # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
+FLOP_PER_LAMBERTIAN_PAIR = 12       # dot 5, max 1, 3 FMA 6
+FLOP_PER_GGX_ACCEPTED = 30
+FLOP_PER_GGX_REJECTED = 8
+FLOP_PER_LUT_SAMPLE = 40
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+class Workload:
+    """One benchmark configuration: how to run a step on this rank and how much
+    work the whole job does."""
+
+    def __init__(self, name, args, ibl, rank, world, dist):
+        import numpy as np
+        import vulkan_renderer_amd as vra
+        from vulkan_renderer_amd import sharding
+        self.name, self.ibl, self.rank, self.world, self.dist = name, ibl, rank, world, dist
+        self.sharding = sharding
+        t = ibl.torch
+        self.kernel_ms = []
+        if name in ("c1", "c4"):
+            self.in_w, self.out_w = (64, 32) if name == "c1" else (1024, 128)
+            strip = vra.synth.hdr_environment(self.in_w, seed=args.seed)
+            rgbe = t.from_numpy(strip).to(ibl.device)
+            self.env = ibl.rgbe_decode(rgbe).reshape(6, self.in_w, self.in_w, 4).contiguous()
+            self.n_out = 6 * self.out_w * self.out_w
+            self.n_in = 6 * self.in_w * self.in_w
+            self.begin, self.count = sharding.shard_range(self.n_out, rank, world)
+            self.out = t.zeros((6, self.out_w, self.out_w, 4), dtype=t.float32, device=ibl.device)
+            self.samples = self.n_out * self.n_in
+            self.flop_per_launch = FLOP_PER_LAMBERTIAN_PAIR * self.count * self.n_in
+            self.kernel = "lambertian_pairs"
+            self.desc = ("C%s: Lambertian irradiance %dx%d/face -> %dx%d/face, all (output, input) texel pairs"
+                         % (name[1], self.in_w, self.in_w, self.out_w, self.out_w))
+            self.bytes_per_launch = 24 * self.n_in + 16 * self.count
+        elif name == "c3":
+            self.in_w, self.min_size = 512, 16
+            strip = vra.synth.hdr_environment(self.in_w, seed=args.seed)
+            rgbe = t.from_numpy(strip).to(ibl.device)
+            self.env = ibl.rgbe_decode(rgbe).reshape(6, self.in_w, self.in_w, 4).contiguous()
+            self.mips = ibl.ggx_mip_levels(self.in_w, self.in_w, self.min_size)
+            self.levels = []
+            for m in range(1, self.mips + 1):
+                ow = self.in_w >> m
+                n_out = 6 * ow * ow
+                b, c = sharding.shard_range(n_out, rank, world)
+                self.levels.append(dict(m=m, ow=ow, n_out=n_out, begin=b, count=c,
+                                        out=t.zeros((6, ow, ow, 4), dtype=t.float32, device=ibl.device)))
+            # work counts, measured once by the counting kernels outside the timed region
+            ibl.set_counting(True)
+            tested = accepted = 0
+            for lv in self.levels:
+                ibl.ggx_level(self.env, lv["ow"], lv["m"], self.mips, out=lv["out"])
+                c = ibl.last_counts()
+                lv["tested"], lv["accepted"] = c["tested"], c["accepted"]
+                tested += c["tested"]
+                accepted += c["accepted"]
+            ibl.set_counting(False)
+            self.samples = tested
+            self.accepted = accepted
+            lv1 = self.levels[0]
+            frac = lv1["count"] / lv1["n_out"]
+            self.flop_per_launch = frac * (FLOP_PER_GGX_ACCEPTED * lv1["accepted"]
+                                           + FLOP_PER_GGX_REJECTED * (lv1["tested"] - lv1["accepted"]))
+            self.kernel = "ggx_pairs (level 1)"
+            self.desc = ("C3: GGX prefilter chain of a 512x512/face environment, %d levels, --input-downscale 1; "
+                         "samples = in-patch texel tests (%.3g tested, %.3g accepted)" % (self.mips, tested, accepted))
+            self.bytes_per_launch = 32 * 6 * self.in_w * self.in_w + 16 * lv1["count"]
+        elif name == "c2":
+            self.s = 32
+            self.n_cells = 256 * 256
+            self.begin, self.count = sharding.shard_range(self.n_cells, rank, world)
+            self.out = t.zeros((256, 256, 2), dtype=t.float32, device=ibl.device)
+            self.samples = self.n_cells * self.s * self.s
+            self.flop_per_launch = FLOP_PER_LUT_SAMPLE * self.count * self.s * self.s
+            self.kernel = "brdf_lut_cells"
+            self.desc = "C2: split-sum BRDF table 256x256 cells, 32x32 = 1024 strata per cell"
+            self.bytes_per_launch = 8 * self.count
+        self.np = np
+
+    def step(self):
+        ibl, d = self.ibl, self.dist
+        if self.name in ("c1", "c4"):
+            ibl.lambertian(self.env, self.out_w, self.begin, self.count, out=self.out)
+            self.kernel_ms.append(ibl.last_kernel_ms() if self.count else 0.0)
+            self.sharding.all_gather_ranges(d, self.out.view(-1, 4), self.n_out, self.rank, self.world)
+        elif self.name == "c3":
+            for lv in self.levels:
+                ibl.ggx_level(self.env, lv["ow"], lv["m"], self.mips, lv["begin"], lv["count"], out=lv["out"])
+                if lv["m"] == 1:
+                    self.kernel_ms.append(ibl.last_kernel_ms() if lv["count"] else 0.0)
+                self.sharding.all_gather_ranges(d, lv["out"].view(-1, 4), lv["n_out"], self.rank, self.world)
+        else:
+            ibl.brdf_lut(256, 256, self.s, seed=1, cell_begin=self.begin, cell_count=self.count, out=self.out)
+            self.kernel_ms.append(ibl.last_kernel_ms() if self.count else 0.0)
+            self.sharding.all_gather_ranges(d, self.out.view(-1, 2), self.n_cells, self.rank, self.world)
+
+
+def cpu_baseline(wl, target_seconds):
+    """Times the CPU oracle (reference-faithful loop) on a bounded sample of the
+    same workload and checks the GPU result on that sample while it is at it."""
+    import numpy as np
+    import oracle
+    ncores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+    env = wl.env.cpu().numpy()
+    if wl.name in ("c1", "c4"):
+        n_out = wl.n_out
+        pilot = min(n_out, 4 * ncores)
+        t0 = time.time()
+        oracle.lambertian(env, wl.out_w, out_begin=n_out // 2, out_count=pilot, faithful=True)
+        rate = pilot / max(time.time() - t0, 1e-3)
+        count = int(max(pilot, min(n_out, rate * target_seconds)))
+        begin = (n_out - count) // 2
+        t0 = time.time()
+        want = oracle.lambertian(env, wl.out_w, out_begin=begin, out_count=count, faithful=True)
+        dt = time.time() - t0
+        got = wl.out.cpu().numpy().reshape(-1, 4)[begin:begin + count]
+        want = want.reshape(-1, 4)[begin:begin + count]
+        units = count * wl.n_in
+        sample = "%d of %d output texels (range %d..%d) x all %d input texels" % (count, n_out, begin, begin + count, wl.n_in)
+    elif wl.name == "c3":
+        lv = wl.levels[1]          # level 2: representative cost, full hemisphere
+        n_out = lv["n_out"]
+        pilot = min(n_out, 4 * ncores)
+        t0 = time.time()
+        _, c = oracle.ggx_level(env, lv["ow"], lv["ow"], lv["m"], wl.mips, out_begin=n_out // 2, out_count=pilot,
+                                want_counts=True)
+        rate = pilot / max(time.time() - t0, 1e-3)
+        count = int(max(pilot, min(n_out, rate * target_seconds)))
+        begin = (n_out - count) // 2
+        t0 = time.time()
+        want, c = oracle.ggx_level(env, lv["ow"], lv["ow"], lv["m"], wl.mips, out_begin=begin, out_count=count,
+                                   want_counts=True)
+        dt = time.time() - t0
+        got = lv["out"].cpu().numpy().reshape(-1, 4)[begin:begin + count]
+        want = want.reshape(-1, 4)[begin:begin + count]
+        units = c["tested"]
+        sample = "level 2 of %d, %d of %d output texels (range %d..%d)" % (wl.mips, count, n_out, begin, begin + count)
+    else:
+        t0 = time.time()
+        rows = 8
+        want = oracle.brdf_lut(256, 256, wl.s, seed=1, mode=oracle.MODE_COUNTER, cell_begin=128 * 256, cell_count=rows * 256)
+        dt = time.time() - t0
+        got = wl.out.cpu().numpy()[128:128 + rows].reshape(-1, 2).astype(np.float64)
+        want = want[128:128 + rows].reshape(-1, 2)
+        units = rows * 256 * wl.s * wl.s
+        sample = "%d of 256 roughness rows" % rows
+        return dict(value=units / dt / 1e9, unit="GSamples/s", cores=ncores, kind="port", sample=sample,
+                    seconds=round(dt, 2), parity=dict(max_abs_err=float(np.abs(got - want).max())))
+    err = np.abs(got[:, :3].astype(np.float64) - want[:, :3]) / np.maximum(np.abs(want[:, :3]), 1e-30)
+    same = float((oracle.rgbe_encode(got) == oracle.rgbe_encode(want)).all(axis=1).mean())
+    return dict(value=units / dt / 1e9, unit="GSamples/s", cores=ncores, kind="port", sample=sample,
+                seconds=round(dt, 2),
+                parity=dict(max_rel_err=float(err.max()), rgbe_byte_identical=same))
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import vulkan_renderer_amd as vra
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    ibl = vra.Ibl(local_rank)
+    ibl.set_timing(True)
+    wl = Workload(args.workload, args, ibl, rank, world, dist)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    wl.kernel_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ibl.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        km = torch.tensor([sum(wl.kernel_ms) / max(len(wl.kernel_ms), 1)], dtype=torch.float64, device=ibl.device)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_ms = float(km.item())
+    else:
+        kernel_ms = sum(wl.kernel_ms) / max(len(wl.kernel_ms), 1)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = wl.samples / (elapsed / args.steps) / 1e9
+        achieved = wl.flop_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "env-prefilter GSamples/s",
+            "value": round(value, 3),
+            "unit": "GSamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.desc, "parallelism": "output-texel ranges over %d GPU(s), one all-gather" % world,
+                       "seed": args.seed},
+            "roofline": {
+                "bound": "fp32_valu",
+                "kernel": wl.kernel,
+                "achieved": round(achieved, 3),
+                "peak": FP32_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4),
+                "kernel_ms": round(kernel_ms, 4),
+                "flop_per_launch": wl.flop_per_launch,
+                "algorithmic_bytes_per_launch": wl.bytes_per_launch,
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@
  *     (cube.cpp:16-29,96).  Faces are square (the reference strides input rows by
  *     the height, cube.cpp:104,264, so nothing else is meaningful).
  *   - "*_dev" functions take DEVICE pointers, enqueue on `stream` (a hipStream_t;
- *     NULL = the library's own stream) and do not synchronise.  They use a
+ *     NULL = the HIP default stream) and do not synchronise.  They use a
  *     per-device workspace the library owns, so calls on one device must not
  *     overlap in time.
  *   - The functions without the suffix take HOST pointers, copy in, run, copy out
@@ -51,9 +51,9 @@ enum {
 
 /* ---- life cycle ---------------------------------------------------------- */
 
-/* Binds the calling process to HIP device `device` (-1: the current device),
- * creates the library stream.  Fails with IBL_ENODEV when no GPU is present:
- * there is no CPU fallback behind this library. */
+/* Binds the calling process to HIP device `device` (-1: the current device).
+ * Fails with IBL_ENODEV when no GPU is present: there is no CPU fallback behind
+ * this library. */
 int ibl_init(int device);
 int ibl_shutdown(void);
 const char* ibl_last_error(void);

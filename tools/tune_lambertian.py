@@ -1,0 +1,56 @@
+"""Times lambertian_pairs for several builds of the library and several values of
+the outputs-per-thread knob, interleaved in one process (variants are extra builds
+of csrc/ under tools/variants/, see the Makefile's EXTRA/LIB variables).
+
+    python tools/tune_lambertian.py [in_w out_w]
+"""
+import ctypes
+import glob
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import vulkan_renderer_amd as vra  # noqa: E402
+from vulkan_renderer_amd import capi  # noqa: E402
+
+
+def load(path):
+    lib = ctypes.CDLL(path)
+    for name, (argtypes, restype) in capi._SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = argtypes, restype
+    assert lib.ibl_init(0) == 0, lib.ibl_last_error()
+    lib.ibl_set_timing(1)
+    return lib
+
+
+def main():
+    in_w = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    out_w = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    ibl = vra.Ibl(0)
+    strip = vra.synth.hdr_environment(in_w, seed=1234)
+    env = ibl.rgbe_decode(torch.from_numpy(strip).cuda()).reshape(6, in_w, in_w, 4).contiguous()
+    out = torch.zeros((6, out_w, out_w, 4), device="cuda")
+    libs = {"main": load(capi.LIB_PATH)}
+    for p in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", "*.so"))):
+        libs[os.path.basename(p)] = load(p)
+    n_out, n_in = 6 * out_w * out_w, 6 * in_w * in_w
+    results = {}
+    for rnd in range(3):
+        for name, lib in libs.items():
+            for p in (4, 8, 16):
+                os.environ["IBL_LAMB_P"] = str(p)
+                rc = lib.ibl_lambertian_dev(env.data_ptr(), in_w, in_w, out_w, 0, n_out, out.data_ptr(), None)
+                assert rc == 0, lib.ibl_last_error()
+                ms = ctypes.c_float()
+                assert lib.ibl_last_kernel_ms(ctypes.byref(ms)) == 0
+                results.setdefault((name, p), []).append(ms.value)
+    for (name, p), v in sorted(results.items()):
+        best = min(v)
+        tf = 12.0 * n_out * n_in / (best * 1e-3) / 1e12
+        print("%-16s P=%-2d  ms min %.3f med %.3f  -> %.1f TFLOP/s (%.1f%% of 157.3)" % (name, p, best, sorted(v)[len(v) // 2], tf, 100 * tf / 157.3))
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,7 @@ struct Buffer {
 struct State {
     bool ready = false;
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // host-buffer entry points run on the default stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, counting = false, timed_valid = false;
     Buffer a, b, pn, partial, counts, stage_in, stage_out;
@@ -74,7 +74,7 @@ int check_ready() {
     return IBL_OK;
 }
 
-hipStream_t pick(void* stream) { return stream ? (hipStream_t)stream : g.stream; }
+hipStream_t pick(void* stream) { return (hipStream_t)stream; }
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
@@ -123,7 +123,6 @@ int ibl_init(int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
     g.device = device;
@@ -139,7 +138,6 @@ int ibl_shutdown(void) {
     release(g.stage_in); release(g.stage_out);
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
-    if (g.stream) (void)hipStreamDestroy(g.stream);
     g = State();
     return IBL_OK;
 }

@@ -9,6 +9,13 @@
 //              d = t*(a2-1)+1                               (cube.cpp:274-290)
 //     out      sum(L_j * weight) / sum(weight)              (cube.cpp:292-305)
 // The constants a2/pi and 1/(1-cutoff)^2 cancel in the quotient and are dropped.
+// For small a2 the denominator d cancels to ~a2 at the lobe centre, so an error of
+// one float ulp in t moves the weight by ~1e-7/a2.  The reference's t is
+// NoH^2 = (|n|^2 + c)^2 / (|n|^2 + |u|^2 + 2c) with the float-normalised n and u it
+// actually holds; to first order that is (1+c)/2 + 3/4 (|n|^2-1) - 1/4 (|u|^2-1).
+// The |n|^2 term is the same for every input texel of one output texel (it would
+// not average out), so it is folded into a per-output constant:
+//     u = (1-c)/2 (exact in float for c >= 1/2),  d = u*(1-a2) + [a2 - (1-a2)*3/4*(|n|^2-1)].
 // A patch is visited only when the reference's own patch test passes for that
 // output texel (cube.cpp:256-258); that test is evaluated per lane in the
 // reference's exact float arithmetic because it changes which texels count.
@@ -120,8 +127,10 @@ __global__ __launch_bounds__(GGX_THREADS, 2) void ggx_pairs(
     const uint32_t y0 = tile_y * (16 * PY) + (tid >> 4) * PY;
 
     float nx[P], ny[P], nz[P];
+    float a2p[P];
     bool valid[P];
     uint32_t lo[P];
+    const float om_a2 = -a2m1;   // 1 - a2
     float sumx = 0.f, sumy = 0.f, sumz = 0.f;
     bool any_valid = false;
 #pragma unroll
@@ -133,6 +142,10 @@ __global__ __launch_bounds__(GGX_THREADS, 2) void ggx_pairs(
         lo[p] = o - out_begin;
         F3 n = ref_normalize(ref_normal_from(face, min(x, out_w - 1), min(y, out_h - 1), out_w, out_h));
         nx[p] = n.x; ny[p] = n.y; nz[p] = n.z;
+        {
+            double eps = ((double)n.x * n.x + (double)n.y * n.y + (double)n.z * n.z) - 1.0;
+            a2p[p] = (float)((1.0 + (double)a2m1) - (double)om_a2 * 0.75 * eps);
+        }
         if (valid[p]) { sumx += n.x; sumy += n.y; sumz += n.z; any_valid = true; }
     }
     if (!__syncthreads_or(any_valid)) return;
@@ -237,9 +250,10 @@ __global__ __launch_bounds__(GGX_THREADS, 2) void ggx_pairs(
                         float c = nx[p] * ta.x;
                         c = fmaf(ny[p], ta.y, c);
                         c = fmaf(nz[p], ta.z, c);
-                        float t = fmaf(0.5f, c, 0.5f);
+                        float u = fmaf(-0.5f, c, 0.5f);
+                        float t = 1.0f - u;
                         float sq = __builtin_amdgcn_sqrtf(t);
-                        float d = fmaf(t, a2m1, 1.0f);
+                        float d = fmaf(u, om_a2, a2p[p]);
                         float qd = (t - cutoff) * __builtin_amdgcn_rcpf(d);
                         float f = (c * sq) * (qd * qd);
                         bool ok = c > thr[p];

@@ -21,6 +21,7 @@
 // bake is bit-identical to an unsharded one.
 #include "ibl_device.h"
 #include "ibl_kernels.h"
+#include <stdlib.h>
 
 namespace ibl {
 
@@ -44,8 +45,12 @@ __global__ __launch_bounds__(256) void lambertian_prep(const float4* __restrict_
     b[j] = make_float2(L.y, L.z);
 }
 
+#ifndef IBL_LAMB_MIN_WAVES
+#define IBL_LAMB_MIN_WAVES 2
+#endif
+
 template <int P>
-__global__ __launch_bounds__(LAMB_THREADS, 2) void lambertian_pairs(
+__global__ __launch_bounds__(LAMB_THREADS, IBL_LAMB_MIN_WAVES) void lambertian_pairs(
     const float4* __restrict__ a, const float2* __restrict__ b, uint32_t n_in, uint32_t slice_len,
     uint32_t out_size, uint32_t out_begin, uint32_t out_count, double* __restrict__ partial) {
     __shared__ float4 s_a[2][LAMB_TILE];
@@ -144,8 +149,12 @@ LambertianPlan lambertian_plan(uint32_t n_in, uint32_t out_count) {
     if (tiles_per_slice < 4) tiles_per_slice = 4;            // at least 1024 texels each
     pl.slice_len = tiles_per_slice * LAMB_TILE;
     pl.n_slices = (n_in + pl.slice_len - 1) / pl.slice_len;
-    // Output texels per thread: as many as still leave >= ~1536 workgroups.
-    int p = 8;
+    // Output texels per thread: as many (up to 4) as still leave >= ~1536 workgroups.
+    int p = 4;   // 4 and 8 run at the same rate; 4 gives twice the workgroups
+    if (const char* e = getenv("IBL_LAMB_P")) {   // tuning knob, not part of the ABI
+        int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) p = v;
+    } else
     while (p > 1) {
         uint64_t blocks = (uint64_t)((out_count + 256u * p - 1) / (256u * p)) * pl.n_slices;
         if (blocks >= 1536) break;
@@ -169,6 +178,7 @@ hipError_t lambertian_launch(const LambertianPlan& pl, const float* d_env, uint3
     dim3 grid(pl.out_blocks, pl.n_slices);
     if (ev0) (void)hipEventRecord(ev0, stream);
     switch (pl.p) {
+        case 16: lambertian_pairs<16><<<grid, LAMB_THREADS, 0, stream>>>((const float4*)d_a, (const float2*)d_b, n_in, pl.slice_len, out_size, out_begin, out_count, d_partial); break;
         case 8: lambertian_pairs<8><<<grid, LAMB_THREADS, 0, stream>>>((const float4*)d_a, (const float2*)d_b, n_in, pl.slice_len, out_size, out_begin, out_count, d_partial); break;
         case 4: lambertian_pairs<4><<<grid, LAMB_THREADS, 0, stream>>>((const float4*)d_a, (const float2*)d_b, n_in, pl.slice_len, out_size, out_begin, out_count, d_partial); break;
         case 2: lambertian_pairs<2><<<grid, LAMB_THREADS, 0, stream>>>((const float4*)d_a, (const float2*)d_b, n_in, pl.slice_len, out_size, out_begin, out_count, d_partial); break;
