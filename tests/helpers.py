@@ -22,3 +22,77 @@ def decode_strip(orc, strip):
     """(6W, W, 4) uint8 -> (6, W, W, 4) float32 through the oracle's decoder."""
     w = strip.shape[1]
     return orc.rgbe_decode(strip).reshape(6, w, w, 4)
+
+
+# ---- a tiny independent PNG codec for the CLI tests (zlib only) -----------------------
+
+def write_png(path, rgba, color_type=6, filters=(0,)):
+    """rgba: (H, W, 4) uint8.  color_type 6 (RGBA) or 2 (RGB); `filters` cycles per row."""
+    import struct
+    import zlib
+    img = np.asarray(rgba, np.uint8)
+    if color_type == 2:
+        img = img[..., :3]
+    h, w, ch = img.shape
+    rows = []
+    prev = np.zeros((w * ch,), np.int32)
+    for y in range(h):
+        cur = img[y].reshape(-1).astype(np.int32)
+        ft = filters[y % len(filters)]
+        left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        upleft = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            out = cur
+        elif ft == 1:
+            out = cur - left
+        elif ft == 2:
+            out = cur - prev
+        elif ft == 3:
+            out = cur - (left + prev) // 2
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            out = cur - pred
+        rows.append(bytes([ft]) + (out & 255).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0))
+    z = zlib.compress(b"".join(rows), 6)
+    half = len(z) // 2
+    data += chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def read_png(path):
+    """-> (H, W, 4) uint8 for the 8-bit RGBA files png_io writes."""
+    import struct
+    import zlib
+    with open(path, "rb") as f:
+        data = f.read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h, ct = 8, b"", 0, 0, 0
+    while pos < len(data):
+        n, t = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(t + body) & 0xffffffff
+        if t == b"IHDR":
+            w, h, depth, ct, _, _, il = struct.unpack(">IIBBBBB", body)
+            assert depth == 8 and ct == 6 and il == 0
+        elif t == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
+    out = np.zeros((h, w * 4), np.int32)
+    for y in range(h):
+        ft, row = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            out[y] = row
+        elif ft == 2:
+            out[y] = (row + (out[y - 1] if y else 0)) & 255
+        else:
+            raise AssertionError("unexpected filter %d" % ft)
+    return out.astype(np.uint8).reshape(h, w, 4)
