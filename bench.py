@@ -9,14 +9,18 @@ the metric ("env-prefilter GSamples/s at 1/2/4/8 MI355X") is quoted on across
 1-8 GPUs: the brute-force Lambertian convolution of a 1024x1024/face environment
 into 128x128/face (6.18e11 (output, input) texel pairs).  With N > 1 (one process
 per GPU, launched by torch.distributed.run) the output texels are split into N
-contiguous ranges, every rank bakes its range against the full input, and one
-RCCL all-gather assembles the cube on every rank; total work is fixed, so the
-scaling is "strong".
+shards that keep mirror-image texels together (the kernel evaluates the 8 sign
+flips of a direction at once), every rank bakes its shard against the full input
+into a zero-filled cube, and one RCCL all-reduce (a sum of disjoint supports, so
+exact) assembles the cube on every rank; total work is fixed, so the scaling is
+"strong".
 
 Rank 0 prints ONE JSON line.  `value` is samples of the whole job per second;
 `roofline` prices the dominant kernel's algorithmic FP32 work (flop per sample x
 samples per launch / that kernel's mean duration from HIP events on its own
-stream) against the 157.3 TFLOP/s FP32 vector peak; `cpu_baseline` is the CPU
+stream) against the 157.3 TFLOP/s FP32 vector peak -- the mirror-octet kernel
+issues fewer instructions than that algorithmic count, so the fraction can exceed
+1 and `executed` prices the instructions it really issues; `cpu_baseline` is the CPU
 oracle (a port of the reference's loop, recomputing the input direction per pair
 as the reference does) timed on a bounded sample of the same workload.
 """
@@ -32,6 +36,8 @@ if ROOT not in sys.path:
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3     # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
 FLOP_PER_LAMBERTIAN_PAIR = 12       # dot 5, max 1, 3 FMA 6
+# the octet kernel issues 3 mul + 8 add + 168 FMA + 1 idle pattern per 64 pairs
+EXECUTED_FLOP_PER_LAMBERTIAN_PAIR = (3 + 8 + 2 * 168) / 64.0
 FLOP_PER_GGX_ACCEPTED = 30
 FLOP_PER_GGX_REJECTED = 8
 FLOP_PER_LUT_SAMPLE = 40
@@ -68,11 +74,14 @@ class Workload:
             self.env = ibl.rgbe_decode(rgbe).reshape(6, self.in_w, self.in_w, 4).contiguous()
             self.n_out = 6 * self.out_w * self.out_w
             self.n_in = 6 * self.in_w * self.in_w
-            self.begin, self.count = sharding.shard_range(self.n_out, rank, world)
+            n_oct = self.n_out // 8
+            _, oct_count = sharding.shard_range(n_oct, rank, world)
+            self.count = oct_count * 8              # output texels this rank bakes
             self.out = t.zeros((6, self.out_w, self.out_w, 4), dtype=t.float32, device=ibl.device)
             self.samples = self.n_out * self.n_in
             self.flop_per_launch = FLOP_PER_LAMBERTIAN_PAIR * self.count * self.n_in
-            self.kernel = "lambertian_pairs"
+            self.executed_flop_per_launch = EXECUTED_FLOP_PER_LAMBERTIAN_PAIR * self.count * self.n_in
+            self.kernel = "lambertian_oct_pairs"
             self.desc = ("C%s: Lambertian irradiance %dx%d/face -> %dx%d/face, all (output, input) texel pairs"
                          % (name[1], self.in_w, self.in_w, self.out_w, self.out_w))
             self.bytes_per_launch = 24 * self.n_in + 16 * self.count
@@ -124,9 +133,12 @@ class Workload:
     def step(self):
         ibl, d = self.ibl, self.dist
         if self.name in ("c1", "c4"):
-            ibl.lambertian(self.env, self.out_w, self.begin, self.count, out=self.out)
+            if self.world > 1:
+                self.out.zero_()
+            ibl.lambertian_shard(self.env, self.out_w, self.rank, self.world, out=self.out)
             self.kernel_ms.append(ibl.last_kernel_ms() if self.count else 0.0)
-            self.sharding.all_gather_ranges(d, self.out.view(-1, 4), self.n_out, self.rank, self.world)
+            if self.world > 1:
+                d.all_reduce(self.out)
         elif self.name == "c3":
             for lv in self.levels:
                 ibl.ggx_level(self.env, lv["ow"], lv["m"], self.mips, lv["begin"], lv["count"], out=lv["out"])
@@ -149,7 +161,7 @@ def cpu_baseline(wl, target_seconds):
     env = wl.env.cpu().numpy()
     if wl.name in ("c1", "c4"):
         n_out = wl.n_out
-        pilot = min(n_out, 4 * ncores)
+        pilot = min(n_out, 32 * ncores)
         t0 = time.time()
         oracle.lambertian(env, wl.out_w, out_begin=n_out // 2, out_count=pilot, faithful=True)
         rate = pilot / max(time.time() - t0, 1e-3)
@@ -165,7 +177,7 @@ def cpu_baseline(wl, target_seconds):
     elif wl.name == "c3":
         lv = wl.levels[1]          # level 2: representative cost, full hemisphere
         n_out = lv["n_out"]
-        pilot = min(n_out, 4 * ncores)
+        pilot = min(n_out, 32 * ncores)
         t0 = time.time()
         _, c = oracle.ggx_level(env, lv["ow"], lv["ow"], lv["m"], wl.mips, out_begin=n_out // 2, out_count=pilot,
                                 want_counts=True)
@@ -212,11 +224,15 @@ def main():
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
                              "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    # Rehearsal knobs for a one-GPU box (not used by the driver): all ranks on cuda:0
+    # over gloo, since RCCL refuses two ranks on one device.
+    backend = os.environ.get("IBL_BENCH_BACKEND", "nccl")
+    if os.environ.get("IBL_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend, rank=rank, world_size=world)
     ibl = vra.Ibl(local_rank)
     ibl.set_timing(True)
     wl = Workload(args.workload, args, ibl, rank, world, dist)
@@ -263,7 +279,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.desc, "parallelism": "output-texel ranges over %d GPU(s), one all-gather" % world,
+            "config": {"workload": wl.desc, "parallelism": "output shards over %d GPU(s), one collective per cube" % world,
                        "seed": args.seed},
             "roofline": {
                 "bound": "fp32_valu",
@@ -274,6 +290,9 @@ def main():
                 "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4),
                 "kernel_ms": round(kernel_ms, 4),
                 "flop_per_launch": wl.flop_per_launch,
+                "executed": (None if not getattr(wl, "executed_flop_per_launch", None) else {
+                    "tflops": round(wl.executed_flop_per_launch / (kernel_ms * 1e-3) / 1e12, 3),
+                    "frac": round(wl.executed_flop_per_launch / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)}),
                 "algorithmic_bytes_per_launch": wl.bytes_per_launch,
                 "traffic": None,
             },

@@ -73,6 +73,15 @@ int ibl_ggx_level_params(uint32_t mip_level, uint32_t mip_levels, uint32_t in_w,
 int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
                        uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
 
+/* The same integral for shard `shard` of `n_shards`: a library-chosen partition of
+ * the output texels that keeps mirror-image texels (+-x, +-y, +-z) on one shard,
+ * because the kernel evaluates them together.  Writes that shard's texels into
+ * their places in the full-size d_out and touches nothing else; the shards are
+ * disjoint and cover the cube, so zero-filled buffers summed over the shards give
+ * the whole result.  A texel's value does not depend on n_shards. */
+int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
+                             uint32_t shard, uint32_t n_shards, float* d_out, void* stream);
+
 /* One iteration of integrateGGX's level loop, cube.cpp:152-309 (no encode, no
  * file).  Rejects min(in_w,in_h) < 16, where the reference divides by a zero
  * patch size (cube.cpp:175,182). */

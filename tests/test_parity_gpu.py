@@ -28,6 +28,18 @@ GGX_TIGHT = 1e-4
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.fixture(params=["octets", "general"])
+def kernel_mode(request, monkeypatch):
+    """Both implementations of the integrals: the mirror-octet kernels (default where
+    the face sizes allow) and the general kernels (forced by IBL_NO_OCTETS=1, which
+    the library reads on every call)."""
+    if request.param == "general":
+        monkeypatch.setenv("IBL_NO_OCTETS", "1")
+    else:
+        monkeypatch.delenv("IBL_NO_OCTETS", raising=False)
+    return request.param
+
+
 def _dev(ibl, arr):
     return ibl.torch.from_numpy(np.ascontiguousarray(arr)).to(ibl.device)
 
@@ -110,7 +122,7 @@ def test_downscale_rejects_bad_factor(ibl, orc):
 # ---- Lambertian --------------------------------------------------------------------------
 
 @pytest.mark.parametrize("w,out", [(16, 8), (64, 32), (32, 5), (128, 16)])
-def test_lambertian_parity(ibl, orc, w, out):
+def test_lambertian_parity(ibl, orc, w, out, kernel_mode):
     env, env_d = _env(ibl, orc, w)
     got = ibl.lambertian(env_d, out).cpu().numpy()
     _check_cube(orc, got, orc.lambertian(env, out))
@@ -124,7 +136,7 @@ def test_lambertian_config1_host_api(ibl, orc):
 
 
 @pytest.mark.parametrize("kind", ["const", "single"])
-def test_lambertian_special_environments(ibl, orc, kind):
+def test_lambertian_special_environments(ibl, orc, kind, kernel_mode):
     env, env_d = _env(ibl, orc, 32, kind=kind)
     got = ibl.lambertian(env_d, 16).cpu().numpy()
     want = orc.lambertian(env, 16)
@@ -137,7 +149,7 @@ def test_lambertian_special_environments(ibl, orc, kind):
     _check_cube(orc, got, want, tight=5e-5 if kind == "single" else 5e-6)
 
 
-def test_lambertian_large_input_subset(ibl, orc):
+def test_lambertian_large_input_subset(ibl, orc, kernel_mode):
     """1024x1024/face input (BASELINE config 4's input), 256 of its 128x128/face
     output texels against the oracle; the full output is covered by
     test_lambertian_full_size_properties."""
@@ -152,7 +164,7 @@ def test_lambertian_large_input_subset(ibl, orc):
     assert (flat[:begin] == 0).all() and (flat[begin + 256:] == 0).all()
 
 
-def test_lambertian_full_size_properties(ibl, orc):
+def test_lambertian_full_size_properties(ibl, orc, kernel_mode):
     """BASELINE config 4 at full size through size-independent properties:
     a sharded bake equals the unsharded one bit for bit, a constant environment
     comes back as (quadrature-exact) that constant, and the operator is linear."""
@@ -170,6 +182,17 @@ def test_lambertian_full_size_properties(ibl, orc):
     cenv, cenv_d = _env(ibl, orc, 1024, kind="const")
     c = ibl.lambertian(cenv_d, 128).cpu().numpy()[..., :3] / cenv[0, 0, 0, :3]
     assert np.abs(c - 1.0).max() < 1e-5      # 1024^2 quadrature of the cosine lobe
+    # shards (mirror-image texels kept together) are disjoint, cover the cube and do
+    # not change any texel: zero-filled buffers summed over the shards equal the bake
+    for n_shards in (1, 3, 8):
+        acc = ibl.torch.zeros_like(full)
+        for sh in range(n_shards):
+            one = ibl.lambertian_shard(env_d, 128, sh, n_shards)
+            assert float(((one != 0) & (acc != 0)).sum()) == 0
+            acc += one
+        assert ibl.torch.equal(acc, full)
+    with pytest.raises(vra.IblError):
+        ibl.lambertian_shard(env_d, 128, 3, 3)
 
 
 # ---- GGX ---------------------------------------------------------------------------------

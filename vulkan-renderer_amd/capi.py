@@ -34,6 +34,7 @@ _SIGNATURES = {
     "ibl_ggx_level_params": ([_u32, _u32, _u32, _u32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_u32)], _int),
     "ibl_lambertian_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_lambertian_shard_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_ggx_level_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_brdf_lut_dev": ([_u32, _u32, _u32, _u64, _int, _u32, _u32, _vp, _vp], _int),
     "ibl_rgbe_decode_dev": ([_vp, _vp, _u32, _vp], _int),
@@ -154,6 +155,14 @@ class Ibl:
             out = self.torch.zeros((6, out_size, out_size, 4), dtype=self.torch.float32, device=self.device)
         self._check(self.lib.ibl_lambertian_dev(_ptr(env), w, h, out_size, out_begin, out_count, _ptr(out),
                                                 self._stream(stream)))
+        return out
+
+    def lambertian_shard(self, env, out_size, shard, n_shards, out=None, stream=None):
+        w, h = self._env(env)
+        if out is None:
+            out = self.torch.zeros((6, out_size, out_size, 4), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.ibl_lambertian_shard_dev(_ptr(env), w, h, out_size, shard, n_shards, _ptr(out),
+                                                      self._stream(stream)))
         return out
 
     def ggx_level(self, env, out_w, mip, mips, out_begin=0, out_count=None, out=None, stream=None, out_h=None):

@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -77,6 +78,15 @@ int check_ready() {
 hipStream_t pick(void* stream) { return (hipStream_t)stream; }
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+// The mirror-octet kernels need even, exactly mirror-symmetric face grids on both
+// sides.  IBL_NO_OCTETS=1 forces the general kernels (used by the tests to cover
+// both).
+bool use_octets(uint32_t in_w, uint32_t out_w) {
+    const char* e = getenv("IBL_NO_OCTETS");
+    if (e && e[0] == '1') return false;
+    return ibl::cube_is_mirror_exact(in_w) && ibl::cube_is_mirror_exact(out_w);
+}
 
 int check_cube(uint32_t w, uint32_t h, const char* what) {
     if (w == 0 || h == 0) return fail(IBL_EINVAL, "%s: empty cube face %ux%u", what, w, h);
@@ -205,13 +215,59 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
     g.last_counts[2] = 0;
     g.counts_pending = false;
     if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
-    ibl::LambertianPlan pl = ibl::lambertian_plan(n_in, out_count);
-    if (int rc = ensure(g.a, pl.prep_bytes_a)) return rc;
-    if (int rc = ensure(g.b, pl.prep_bytes_b)) return rc;
-    if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
     hipStream_t s = pick(stream);
-    HIP_TRY(ibl::lambertian_launch(pl, d_env, in_w, in_h, out_size, out_begin, out_count, d_out, g.a.ptr, g.b.ptr,
-                                   (double*)g.partial.ptr, s, g.timing ? g.ev0 : nullptr, g.timing ? g.ev1 : nullptr));
+    if (use_octets(in_w, out_size)) {
+        // mirror-octet kernel over every output octet; texels outside the range are masked
+        const uint32_t n_oct = 3 * (out_size / 2) * (out_size / 2);
+        ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, out_size, n_oct);
+        if (int rc = ensure(g.a, pl.rec_bytes)) return rc;
+        if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
+        HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, 0, n_oct, out_begin, out_count, d_out, g.a.ptr,
+                                           (double*)g.partial.ptr, s, g.timing ? g.ev0 : nullptr,
+                                           g.timing ? g.ev1 : nullptr));
+    } else {
+        ibl::LambertianPlan pl = ibl::lambertian_plan(n_in, out_count);
+        if (int rc = ensure(g.a, pl.prep_bytes_a)) return rc;
+        if (int rc = ensure(g.b, pl.prep_bytes_b)) return rc;
+        if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
+        HIP_TRY(ibl::lambertian_launch(pl, d_env, in_w, in_h, out_size, out_begin, out_count, d_out, g.a.ptr, g.b.ptr,
+                                       (double*)g.partial.ptr, s, g.timing ? g.ev0 : nullptr,
+                                       g.timing ? g.ev1 : nullptr));
+    }
+    g.timed_valid = g.timing;
+    return IBL_OK;
+}
+
+int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
+                             uint32_t shard, uint32_t n_shards, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_env || !d_out) return fail(IBL_EINVAL, "lambertian: null pointer");
+    if (int rc = check_cube(in_w, in_h, "lambertian input")) return rc;
+    if (int rc = check_cube(out_size, out_size, "lambertian output")) return rc;
+    if (n_shards == 0 || shard >= n_shards) return fail(IBL_EINVAL, "lambertian: shard %u of %u", shard, n_shards);
+    const uint32_t n_out = out_size * out_size * 6;
+    if (!use_octets(in_w, out_size)) {
+        // no mirror symmetry to keep together: shards are plain (face, y, x) ranges
+        const uint32_t per = (n_out + n_shards - 1) / n_shards;
+        const uint32_t begin = shard * per < n_out ? shard * per : n_out;
+        const uint32_t count = per < n_out - begin ? per : n_out - begin;
+        return ibl_lambertian_dev(d_env, in_w, in_h, out_size, begin, count, d_out, stream);
+    }
+    const uint32_t n_oct = 3 * (out_size / 2) * (out_size / 2);
+    const uint32_t per = (n_oct + n_shards - 1) / n_shards;
+    const uint32_t begin = shard * per < n_oct ? shard * per : n_oct;
+    const uint32_t count = per < n_oct - begin ? per : n_oct - begin;
+    g.last_counts[0] = 0;
+    g.last_counts[1] = (uint64_t)count * 8 * in_w * in_h * 6;
+    g.last_counts[2] = 0;
+    g.counts_pending = false;
+    if (count == 0) { g.timed_valid = false; return IBL_OK; }
+    ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, out_size, count);
+    if (int rc = ensure(g.a, pl.rec_bytes)) return rc;
+    if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
+    HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, begin, count, 0, n_out, d_out, g.a.ptr,
+                                       (double*)g.partial.ptr, pick(stream), g.timing ? g.ev0 : nullptr,
+                                       g.timing ? g.ev1 : nullptr));
     g.timed_valid = g.timing;
     return IBL_OK;
 }

@@ -83,3 +83,52 @@ __device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
     asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+
+// ---- mirror octets -------------------------------------------------------------
+// The texel-centre directions of a cube map with even face size are closed under
+// the 8 sign flips (+-x, +-y, +-z).  An "octet" is such a group of 8 texels; it is
+// named by (axis, j, i): the pair of faces it lies on (0: +-X, 1: +-Y, 2: +-Z) and
+// the row/column (j, i) < (H/2, W/2) of its member in the top-left face quadrant.
+// Member sigma (bit 0/1/2 set = x/y/z component negative) of that octet is the
+// texel returned here; it follows from the face table of getNormalFrom
+// (cube.cpp:35-46) with s(i) < 0 for i < W/2 and s(W-1-i) = -s(i).
+struct Texel { uint32_t face, x, y; };
+
+__host__ __device__ inline Texel octet_member(uint32_t axis, uint32_t j, uint32_t i, uint32_t sigma,
+                                              uint32_t w, uint32_t h) {
+    const bool nx = sigma & 1u, ny = sigma & 2u, nz = sigma & 4u;
+    const uint32_t xi = i, xm = w - 1 - i, yj = j, ym = h - 1 - j;
+    Texel t;
+    if (axis == 0) {
+        t.face = nx ? 1u : 0u;
+        t.y = ny ? ym : yj;
+        t.x = (t.face == 0) ? (nz ? xm : xi) : (nz ? xi : xm);
+    } else if (axis == 1) {
+        t.face = ny ? 3u : 2u;
+        t.x = nx ? xi : xm;
+        t.y = (t.face == 2) ? (nz ? yj : ym) : (nz ? ym : yj);
+    } else {
+        t.face = nz ? 5u : 4u;
+        t.y = ny ? ym : yj;
+        t.x = (t.face == 4) ? (nx ? xi : xm) : (nx ? xm : xi);
+    }
+    return t;
+}
+
+// v_add_f32 / v_sub_f32 with the clamp output modifier (result clamped to [0, 1]).
+__device__ __forceinline__ float add_clamp01(float a, float b) {
+    float r;
+    asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float sub_clamp01(float a, float b) {
+    float r;
+    asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max(0, min(1, -a - b))
+__device__ __forceinline__ float neg_sub_clamp01(float a, float b) {
+    float r;
+    asm("v_sub_f32_e64 %0, -%1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}

@@ -22,6 +22,23 @@ hipError_t lambertian_launch(const LambertianPlan& pl, const float* d_env, uint3
                              void* d_a, void* d_b, double* d_partial, hipStream_t stream,
                              hipEvent_t ev0, hipEvent_t ev1);
 
+// Mirror-octet form of the same integral (lambertian_octets.hip); needs even,
+// mirror-exact face sizes on both sides.
+bool cube_is_mirror_exact(uint32_t w);
+struct LambertianOctPlan {
+    uint32_t n_oct_in;     // 3 * (in_w/2)^2
+    uint32_t slice_len;    // input octets per slice
+    uint32_t n_slices;
+    uint32_t out_blocks;
+    size_t partial_bytes;  // [slice][24][oct_count] double
+    size_t rec_bytes;      // 7 float4 per input octet
+};
+LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_size, uint32_t oct_count);
+hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
+                                 uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+                                 float* d_out, void* d_rec, double* d_partial, hipStream_t stream,
+                                 hipEvent_t ev0, hipEvent_t ev1);
+
 struct GgxLevel {          // cube.cpp:161-175
     float roughness, alpha2, cutoff;
     uint32_t patch;        // patch edge in texels

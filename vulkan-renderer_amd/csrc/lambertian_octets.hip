@@ -1,0 +1,242 @@
+// Lambertian irradiance through the cube's mirror symmetry (gfx950).
+//
+// Same sum as lambertian.hip (integrateLambertian, src/utilities/cube.cpp:95-129),
+// evaluated octet against octet.  With canonical (all-positive) components of an
+// output direction n and of a folded input direction g = w/|w|^4, the dot product
+// of output member so with input member si is  tx*a + ty*b + tz*c  with
+// a = nx*gx, b = ny*gy, c = nz*gz and t = so (x) si (component-wise sign product).
+// So 3 multiplies, 2 adds and 6 clamped adds give all 64 dot products of an
+// (output octet, input octet) pair (the pattern t = (-,-,-) is never positive),
+// and what remains is the 56 x 3 colour FMAs: 180 VALU instructions per 64 texel
+// pairs instead of 384.  The reference computes each of those 64 products with the
+// same operands in the same order, so sharing them changes nothing it could see.
+//
+// Kernel plan
+//   lambertian_oct_prep    one thread per input octet: canonical g and the 8
+//                          members' radiance packed as 7 float4 (112 B).
+//   lambertian_oct_pairs   grid = (blocks of 256 output octets) x (input slices);
+//                          a thread owns one output octet: 24 FP32 sums over one
+//                          LDS tile of 64 input octets, then FP64 running sums.
+//   lambertian_oct_final   per output octet: slices summed in order in FP64,
+//                          scaled, scattered to the 8 member texels that lie in the
+//                          requested (face, y, x) range.
+// A texel's value does not depend on the range or shard a call covers.
+#include "ibl_device.h"
+#include "ibl_kernels.h"
+
+namespace ibl {
+
+constexpr int OCT_TILE = 64;          // input octets per LDS tile (7 float4 each)
+constexpr int OCT_THREADS = 256;
+constexpr int OCT_REC = 7;            // float4 per input octet record
+
+// s(i) = -s(w-1-i) exactly for every column: true for every power of two, checked
+// for the rest (getNormalFrom evaluates s in double and rounds once, cube.cpp:32).
+bool cube_is_mirror_exact(uint32_t w) {
+    if (w < 2 || (w & 1u)) return false;
+    for (uint32_t i = 0; i < w / 2; i++) {
+        volatile float a = (float)((((double)(float)i + 0.5) / (double)(float)w) * 2.0 - 1.0);
+        volatile float b = (float)((((double)(float)(w - 1 - i) + 0.5) / (double)(float)w) * 2.0 - 1.0);
+        if (!(a == -b) || !(a < 0.0f)) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void lambertian_oct_prep(const float4* __restrict__ env, uint32_t w, uint32_t h,
+                                                            uint32_t n_oct, float4* __restrict__ rec) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_oct) return;
+    const uint32_t hw = w / 2, hh = h / 2;
+    uint32_t axis = k / (hw * hh);
+    uint32_t rem = k - axis * (hw * hh);
+    uint32_t j = rem / hw, i = rem - j * hw;
+    Texel c = octet_member(axis, j, i, 0, w, h);
+    F3 d = ref_normal_from(c.face, c.x, c.y, w, h);       // all components > 0
+    float l2 = ref_dot(d, d);
+    float inv = 1.0f / (l2 * l2);
+    float v[28];
+    v[0] = d.x * inv; v[1] = d.y * inv; v[2] = d.z * inv;
+#pragma unroll
+    for (uint32_t s = 0; s < 8; s++) {
+        Texel t = octet_member(axis, j, i, s, w, h);
+        float4 L = env[(t.face * h + t.y) * h + t.x];     // cube.cpp:104 row stride
+        v[3 + 3 * s] = L.x; v[4 + 3 * s] = L.y; v[5 + 3 * s] = L.z;
+    }
+    v[27] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < OCT_REC; q++)
+        rec[(size_t)k * OCT_REC + q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// Bit mask of the members of output octet (axis, j, i) whose (face, y, x) index
+// lies in [out_begin, out_begin + out_count).
+__device__ __forceinline__ uint32_t octet_range_mask(uint32_t axis, uint32_t j, uint32_t i, uint32_t w,
+                                                      uint32_t out_begin, uint32_t out_count) {
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < 8; s++) {
+        Texel t = octet_member(axis, j, i, s, w, w);
+        uint32_t o = (t.face * w + t.y) * w + t.x;
+        if (o - out_begin < out_count) m |= 1u << s;      // unsigned wrap handles o < out_begin
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(OCT_THREADS, 2) void lambertian_oct_pairs(
+    const float4* __restrict__ rec, uint32_t n_oct_in, uint32_t slice_len,
+    uint32_t out_size, uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+    double* __restrict__ partial) {
+    __shared__ float4 s_rec[2][OCT_TILE * OCT_REC];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t slice = blockIdx.y;
+    const uint32_t in0 = slice * slice_len;
+    const uint32_t in1 = min(n_oct_in, in0 + slice_len);
+    const uint32_t n_tiles = (in1 - in0 + OCT_TILE - 1) / OCT_TILE;
+
+    const uint32_t lo = blockIdx.x * OCT_THREADS + tid;              // local output octet
+    const uint32_t hw = out_size / 2;
+    const uint32_t oo = oct_begin + min(lo, oct_count - 1);
+    const uint32_t axis = oo / (hw * hw);
+    const uint32_t rem = oo - axis * (hw * hw);
+    const uint32_t oj = rem / hw, oi = rem - oj * hw;
+    uint32_t mask = lo < oct_count ? octet_range_mask(axis, oj, oi, out_size, out_begin, out_count) : 0u;
+    if (!__syncthreads_or(mask != 0u)) return;
+
+    Texel c = octet_member(axis, oj, oi, 0, out_size, out_size);
+    const F3 n = ref_normalize(ref_normal_from(c.face, c.x, c.y, out_size, out_size));   // cube.cpp:97
+
+    float acc[8][3];
+    double dacc[8][3];
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { acc[s][k] = 0.0f; dacc[s][k] = 0.0; }
+
+    // Tile staging: OCT_TILE*OCT_REC = 448 float4 per tile, two per thread.
+    auto fetch = [&](uint32_t tile, float4& v0, float4& v1) {
+        const size_t base = ((size_t)in0 + (size_t)tile * OCT_TILE) * OCT_REC;
+        const uint32_t lim = (min(in1 - (in0 + tile * OCT_TILE), (uint32_t)OCT_TILE)) * OCT_REC;
+        v0 = tid < lim ? rec[base + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v1 = (tid + OCT_THREADS < lim) ? rec[base + tid + OCT_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 v0, v1;
+    fetch(0, v0, v1);
+    s_rec[0][tid] = v0;
+    if (tid + OCT_THREADS < OCT_TILE * OCT_REC) s_rec[0][tid + OCT_THREADS] = v1;
+    __syncthreads();
+
+    for (uint32_t tile = 0; tile < n_tiles; tile++) {
+        const int cur = tile & 1;
+        if (tile + 1 < n_tiles) fetch(tile + 1, v0, v1);
+#pragma unroll 2
+        for (int e = 0; e < OCT_TILE; e++) {
+            float r[28];
+#pragma unroll
+            for (int q = 0; q < OCT_REC; q++) {
+                const float4 t4 = s_rec[cur][e * OCT_REC + q];
+                r[4 * q] = t4.x; r[4 * q + 1] = t4.y; r[4 * q + 2] = t4.z; r[4 * q + 3] = t4.w;
+            }
+            const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
+            const float s1 = a + b, s2 = a - b;
+            float t[7];
+            t[0] = s1 + cc;                  // (+,+,+)
+            t[1] = sub_clamp01(cc, s2);      // (-,+,+): -a+b+c
+            t[2] = add_clamp01(s2, cc);      // (+,-,+):  a-b+c
+            t[3] = sub_clamp01(cc, s1);      // (-,-,+): -a-b+c
+            t[4] = sub_clamp01(s1, cc);      // (+,+,-):  a+b-c
+            t[5] = neg_sub_clamp01(s2, cc);  // (-,+,-): -a+b-c
+            t[6] = sub_clamp01(s2, cc);      // (+,-,-):  a-b-c
+#pragma unroll
+            for (int so = 0; so < 8; so++) {
+#pragma unroll
+                for (int si = 0; si < 8; si++) {
+                    const int tau = so ^ si;
+                    if (tau == 7) continue;  // (-,-,-): never positive
+#pragma unroll
+                    for (int k = 0; k < 3; k++) acc[so][k] = fmaf(t[tau], r[3 + 3 * si + k], acc[so][k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dacc[s][k] += (double)acc[s][k]; acc[s][k] = 0.0f; }
+        if (tile + 1 < n_tiles) {
+            s_rec[cur ^ 1][tid] = v0;
+            if (tid + OCT_THREADS < OCT_TILE * OCT_REC) s_rec[cur ^ 1][tid + OCT_THREADS] = v1;
+        }
+        __syncthreads();
+    }
+
+    if (lo < oct_count) {
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                partial[((size_t)slice * 24 + (s * 3 + k)) * oct_count + lo] = dacc[s][k];
+    }
+}
+
+__global__ __launch_bounds__(256) void lambertian_oct_final(const double* __restrict__ partial, uint32_t n_slices,
+                                                             uint32_t out_size, uint32_t oct_begin, uint32_t oct_count,
+                                                             uint32_t out_begin, uint32_t out_count, double scale,
+                                                             float4* __restrict__ out) {
+    uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lo >= oct_count) return;
+    const uint32_t hw = out_size / 2;
+    const uint32_t oo = oct_begin + lo;
+    const uint32_t axis = oo / (hw * hw);
+    const uint32_t rem = oo - axis * (hw * hw);
+    const uint32_t oj = rem / hw, oi = rem - oj * hw;
+    for (uint32_t s = 0; s < 8; s++) {
+        Texel t = octet_member(axis, oj, oi, s, out_size, out_size);
+        uint32_t o = (t.face * out_size + t.y) * out_size + t.x;
+        if (o - out_begin >= out_count) continue;
+        double v[3];
+        for (uint32_t k = 0; k < 3; k++) {
+            double sum = 0.0;
+            for (uint32_t sl = 0; sl < n_slices; sl++) sum += partial[((size_t)sl * 24 + (s * 3 + k)) * oct_count + lo];
+            v[k] = sum * scale;
+        }
+        out[o] = make_float4((float)v[0], (float)v[1], (float)v[2], 0.0f);
+    }
+}
+
+// ---- launch plan -----------------------------------------------------------
+
+LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_size, uint32_t oct_count) {
+    LambertianOctPlan pl;
+    pl.n_oct_in = 3 * (in_w / 2) * (in_w / 2);
+    // Slice length depends on the input size only (range/shard independence).
+    uint32_t tiles = (pl.n_oct_in + OCT_TILE - 1) / OCT_TILE;
+    uint32_t tiles_per_slice = (tiles + 127) / 128;          // at most 128 slices
+    if (tiles_per_slice < 2) tiles_per_slice = 2;
+    pl.slice_len = tiles_per_slice * OCT_TILE;
+    pl.n_slices = (pl.n_oct_in + pl.slice_len - 1) / pl.slice_len;
+    pl.out_blocks = (oct_count + OCT_THREADS - 1) / OCT_THREADS;
+    pl.partial_bytes = (size_t)pl.n_slices * 24 * oct_count * sizeof(double);
+    pl.rec_bytes = (size_t)pl.n_oct_in * OCT_REC * sizeof(float4);
+    (void)out_size;
+    return pl;
+}
+
+hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
+                                 uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+                                 float* d_out, void* d_rec, double* d_partial, hipStream_t stream,
+                                 hipEvent_t ev0, hipEvent_t ev1) {
+    lambertian_oct_prep<<<(pl.n_oct_in + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, in_w, pl.n_oct_in,
+                                                                       (float4*)d_rec);
+    dim3 grid(pl.out_blocks, pl.n_slices);
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    lambertian_oct_pairs<<<grid, OCT_THREADS, 0, stream>>>((const float4*)d_rec, pl.n_oct_in, pl.slice_len, out_size,
+                                                           oct_begin, oct_count, out_begin, out_count, d_partial);
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);
+    lambertian_oct_final<<<(oct_count + 255) / 256, 256, 0, stream>>>(d_partial, pl.n_slices, out_size, oct_begin,
+                                                                      oct_count, out_begin, out_count, scale,
+                                                                      (float4*)d_out);
+    return hipGetLastError();
+}
+
+}  // namespace ibl
