@@ -95,8 +95,8 @@ class Workload:
             for m in range(1, self.mips + 1):
                 ow = self.in_w >> m
                 n_out = 6 * ow * ow
-                b, c = sharding.shard_range(n_out, rank, world)
-                self.levels.append(dict(m=m, ow=ow, n_out=n_out, begin=b, count=c,
+                _, oc = sharding.shard_range(n_out // 8, rank, world)
+                self.levels.append(dict(m=m, ow=ow, n_out=n_out, count=oc * 8,
                                         out=t.zeros((6, ow, ow, 4), dtype=t.float32, device=ibl.device)))
             # work counts, measured once by the counting kernels outside the timed region
             ibl.set_counting(True)
@@ -114,7 +114,7 @@ class Workload:
             frac = lv1["count"] / lv1["n_out"]
             self.flop_per_launch = frac * (FLOP_PER_GGX_ACCEPTED * lv1["accepted"]
                                            + FLOP_PER_GGX_REJECTED * (lv1["tested"] - lv1["accepted"]))
-            self.kernel = "ggx_pairs (level 1)"
+            self.kernel = "ggx_oct_pairs (level 1)"
             self.desc = ("C3: GGX prefilter chain of a 512x512/face environment, %d levels, --input-downscale 1; "
                          "samples = in-patch texel tests (%.3g tested, %.3g accepted)" % (self.mips, tested, accepted))
             self.bytes_per_launch = 32 * 6 * self.in_w * self.in_w + 16 * lv1["count"]
@@ -141,10 +141,13 @@ class Workload:
                 d.all_reduce(self.out)
         elif self.name == "c3":
             for lv in self.levels:
-                ibl.ggx_level(self.env, lv["ow"], lv["m"], self.mips, lv["begin"], lv["count"], out=lv["out"])
+                if self.world > 1:
+                    lv["out"].zero_()
+                ibl.ggx_level_shard(self.env, lv["ow"], lv["m"], self.mips, self.rank, self.world, out=lv["out"])
                 if lv["m"] == 1:
                     self.kernel_ms.append(ibl.last_kernel_ms() if lv["count"] else 0.0)
-                self.sharding.all_gather_ranges(d, lv["out"].view(-1, 4), lv["n_out"], self.rank, self.world)
+                if self.world > 1:
+                    d.all_reduce(lv["out"])
         else:
             ibl.brdf_lut(256, 256, self.s, seed=1, cell_begin=self.begin, cell_count=self.count, out=self.out)
             self.kernel_ms.append(ibl.last_kernel_ms() if self.count else 0.0)

@@ -89,6 +89,12 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
                       uint32_t mip_level, uint32_t mip_levels,
                       uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
 
+/* The same level for shard `shard` of `n_shards`; semantics as
+ * ibl_lambertian_shard_dev. */
+int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                            uint32_t mip_level, uint32_t mip_levels,
+                            uint32_t shard, uint32_t n_shards, float* d_out, void* stream);
+
 /* generateGGXLUT's cell loop, cube.cpp:346-385 (no printing): d_out is
  * [n_rough][n_cos][2] float32 (slope, bias). */
 int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,

@@ -198,7 +198,7 @@ def test_lambertian_full_size_properties(ibl, orc, kernel_mode):
 # ---- GGX ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("w,min_size", [(16, 8), (64, 16), (64, 4), (128, 16)])
-def test_ggx_chain_parity(ibl, orc, w, min_size):
+def test_ggx_chain_parity(ibl, orc, w, min_size, kernel_mode):
     env, env_d = _env(ibl, orc, w)
     mips = orc.ggx_mip_levels(w, w, min_size)
     assert mips == ibl.ggx_mip_levels(w, w, min_size) and mips >= 1
@@ -209,7 +209,7 @@ def test_ggx_chain_parity(ibl, orc, w, min_size):
 
 
 @pytest.mark.parametrize("kind", ["const", "single"])
-def test_ggx_special_environments(ibl, orc, kind):
+def test_ggx_special_environments(ibl, orc, kind, kernel_mode):
     env, env_d = _env(ibl, orc, 64, kind=kind)
     for m in (1, 2):
         got = ibl.ggx_level(env_d, 64 >> m, m, 2).cpu().numpy()
@@ -219,7 +219,7 @@ def test_ggx_special_environments(ibl, orc, kind):
         _check_cube(orc, got, want, tight=GGX_TIGHT)
 
 
-def test_ggx_counts_match_oracle(ibl, orc):
+def test_ggx_counts_match_oracle(ibl, orc, kernel_mode):
     env, env_d = _env(ibl, orc, 64)
     ibl.set_counting(True)
     try:
@@ -234,7 +234,7 @@ def test_ggx_counts_match_oracle(ibl, orc):
         ibl.set_counting(False)
 
 
-def test_ggx_512_subset_16x16_patches(ibl, orc):
+def test_ggx_512_subset_16x16_patches(ibl, orc, kernel_mode):
     """BASELINE config 3's input (512x512/face, 16x16 patches): a band of output
     texels of every level against the oracle."""
     env, env_d = _env(ibl, orc, 512, seed=5)
@@ -251,7 +251,7 @@ def test_ggx_512_subset_16x16_patches(ibl, orc):
         _check_cube(orc, got, want, sel=slice(begin, begin + count), tight=GGX_TIGHT, label="ggx 512 level %d" % m)
 
 
-def test_ggx_full_size_properties(ibl, orc):
+def test_ggx_full_size_properties(ibl, orc, kernel_mode):
     """Config 3 at full size (levels 2-5; level 1 is covered by the subset test and
     by the benchmark): sharded == unsharded bit for bit, constant in = constant out,
     scaling the radiance scales the result exactly."""
@@ -269,6 +269,13 @@ def test_ggx_full_size_properties(ibl, orc):
         assert ibl.torch.equal(ibl.ggx_level(env_d * 4.0, ow, m, 5), full * 4.0)
         c = ibl.ggx_level(cenv_d, ow, m, 5).cpu().numpy()[..., :3] / cenv[0, 0, 0, :3]
         assert np.abs(c - 1.0).max() < 1e-6
+        for n_shards in (1, 3, 8):
+            acc = ibl.torch.zeros_like(full)
+            for sh in range(n_shards):
+                one = ibl.ggx_level_shard(env_d, ow, m, 5, sh, n_shards)
+                assert float(((one != 0) & (acc != 0)).sum()) == 0
+                acc += one
+            assert ibl.torch.equal(acc, full)
 
 
 def test_ggx_rejects_small_and_bad_levels(ibl, orc):

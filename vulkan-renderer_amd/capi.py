@@ -36,6 +36,7 @@ _SIGNATURES = {
     "ibl_lambertian_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_lambertian_shard_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_ggx_level_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_ggx_level_shard_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_brdf_lut_dev": ([_u32, _u32, _u32, _u64, _int, _u32, _u32, _vp, _vp], _int),
     "ibl_rgbe_decode_dev": ([_vp, _vp, _u32, _vp], _int),
     "ibl_rgbe_encode_dev": ([_vp, _vp, _u32, _vp], _int),
@@ -175,6 +176,14 @@ class Ibl:
             out = self.torch.zeros((6, out_h, out_w, 4), dtype=self.torch.float32, device=self.device)
         self._check(self.lib.ibl_ggx_level_dev(_ptr(env), w, h, out_w, out_h, mip, mips, out_begin, out_count,
                                                _ptr(out), self._stream(stream)))
+        return out
+
+    def ggx_level_shard(self, env, out_w, mip, mips, shard, n_shards, out=None, stream=None):
+        w, h = self._env(env)
+        if out is None:
+            out = self.torch.zeros((6, out_w, out_w, 4), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.ibl_ggx_level_shard_dev(_ptr(env), w, h, out_w, out_w, mip, mips, shard, n_shards,
+                                                     _ptr(out), self._stream(stream)))
         return out
 
     def brdf_lut(self, n_rough=256, n_cos=256, samples_sqrt=32, seed=0, mode=LUT_JITTER_COUNTER,

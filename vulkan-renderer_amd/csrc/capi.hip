@@ -272,10 +272,10 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
     return IBL_OK;
 }
 
-int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
-                      uint32_t mip_level, uint32_t mip_levels,
-                      uint32_t out_begin, uint32_t out_count, float* d_out, void* stream) {
-    if (int rc = check_ready()) return rc;
+namespace {
+
+int ggx_check(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+              uint32_t mip_level, uint32_t mip_levels, const float* d_out, uint32_t* patch) {
     if (!d_env || !d_out) return fail(IBL_EINVAL, "ggx: null pointer");
     if (int rc = check_cube(in_w, in_h, "ggx input")) return rc;
     if (int rc = check_cube(out_w, out_h, "ggx output")) return rc;
@@ -283,32 +283,106 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
         return fail(IBL_EINVAL, "ggx: input faces must be at least 16x16 (patch size would be 0), got %u", in_w);
     if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
         return fail(IBL_EINVAL, "ggx: level %u of %u is out of range", mip_level, mip_levels);
+    ibl::GgxLevel lv = ibl::ggx_level_params(mip_level, mip_levels, in_w, in_h);
+    if (in_w % lv.patch != 0)
+        return fail(IBL_EINVAL, "ggx: input width %u is not a multiple of its patch size %u", in_w, lv.patch);
+    *patch = lv.patch;
+    return IBL_OK;
+}
+
+bool use_ggx_octets(uint32_t in_w, uint32_t out_w, uint32_t patch) {
+    const char* e = getenv("IBL_NO_OCTETS");
+    if (e && e[0] == '1') return false;
+    return ibl::ggx_octets_eligible(in_w, out_w, patch);
+}
+
+int ggx_counts_buffer(hipStream_t s, unsigned long long** d_counts) {
+    *d_counts = nullptr;
+    if (!g.counting) return IBL_OK;
+    if (int rc = ensure(g.counts, 4 * sizeof(unsigned long long))) return rc;
+    *d_counts = (unsigned long long*)g.counts.ptr;
+    HIP_TRY(hipMemsetAsync(*d_counts, 0, 4 * sizeof(unsigned long long), s));
+    return IBL_OK;
+}
+
+// Octet kernel over output octets [oct_begin, oct_begin+oct_count), writing the member
+// texels inside [out_begin, out_begin+out_count).
+int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                   uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count, float* d_out,
+                   hipStream_t s) {
+    ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, oct_count);
+    if (int rc = ensure(g.a, pl.rec_bytes)) return rc;
+    if (int rc = ensure(g.pn, pl.pn_bytes)) return rc;
+    if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
+    unsigned long long* d_counts = nullptr;
+    if (int rc = ggx_counts_buffer(s, &d_counts)) return rc;
+    HIP_TRY(ibl::ggx_oct_launch(pl, d_env, in_w, out_w, oct_begin, oct_count, out_begin, out_count, d_out, g.a.ptr,
+                                g.pn.ptr, (double*)g.partial.ptr, d_counts, s, g.timing ? g.ev0 : nullptr,
+                                g.timing ? g.ev1 : nullptr));
+    g.timed_valid = g.timing;
+    g.counts_pending = g.counting;
+    return IBL_OK;
+}
+
+}  // namespace
+
+int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                      uint32_t mip_level, uint32_t mip_levels,
+                      uint32_t out_begin, uint32_t out_count, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    uint32_t patch = 0;
+    if (int rc = ggx_check(d_env, in_w, in_h, out_w, out_h, mip_level, mip_levels, d_out, &patch)) return rc;
     const uint64_t n_out = (uint64_t)out_w * out_h * 6;
     if (int rc = check_range(out_begin, out_count, n_out, "ggx")) return rc;
-    ibl::GgxPlan pl = ibl::ggx_plan(in_w, in_h, out_w, out_h, mip_level, mip_levels, out_count);
-    if (in_w % pl.lv.patch != 0)
-        return fail(IBL_EINVAL, "ggx: input width %u is not a multiple of its patch size %u", in_w, pl.lv.patch);
-    g.last_counts[0] = (uint64_t)out_count * pl.n_patches;
+    const uint32_t n_patches = 6 * (in_w / patch) * (in_h / patch);
+    g.last_counts[0] = (uint64_t)out_count * n_patches;
     g.last_counts[1] = g.last_counts[2] = 0;
     g.counts_pending = false;
     if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
+    hipStream_t s = pick(stream);
+    if (use_ggx_octets(in_w, out_w, patch)) {
+        const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
+        return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, 0, n_oct, out_begin, out_count, d_out, s);
+    }
+    ibl::GgxPlan pl = ibl::ggx_plan(in_w, in_h, out_w, out_h, mip_level, mip_levels, out_count);
     if (int rc = ensure(g.a, pl.prep_bytes_a)) return rc;
     if (int rc = ensure(g.b, pl.prep_bytes_b)) return rc;
     if (int rc = ensure(g.pn, pl.prep_bytes_pn)) return rc;
     if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
-    hipStream_t s = pick(stream);
     unsigned long long* d_counts = nullptr;
-    if (g.counting) {
-        if (int rc = ensure(g.counts, 4 * sizeof(unsigned long long))) return rc;
-        d_counts = (unsigned long long*)g.counts.ptr;
-        HIP_TRY(hipMemsetAsync(d_counts, 0, 4 * sizeof(unsigned long long), s));
-    }
+    if (int rc = ggx_counts_buffer(s, &d_counts)) return rc;
     HIP_TRY(ibl::ggx_launch(pl, d_env, in_w, in_h, out_w, out_h, out_begin, out_count, d_out, g.a.ptr, g.b.ptr,
                             g.pn.ptr, (double*)g.partial.ptr, d_counts, s, g.timing ? g.ev0 : nullptr,
                             g.timing ? g.ev1 : nullptr));
     g.timed_valid = g.timing;
     g.counts_pending = g.counting;
     return IBL_OK;
+}
+
+int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
+                            uint32_t mip_level, uint32_t mip_levels,
+                            uint32_t shard, uint32_t n_shards, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    uint32_t patch = 0;
+    if (int rc = ggx_check(d_env, in_w, in_h, out_w, out_h, mip_level, mip_levels, d_out, &patch)) return rc;
+    if (n_shards == 0 || shard >= n_shards) return fail(IBL_EINVAL, "ggx: shard %u of %u", shard, n_shards);
+    const uint32_t n_out = out_w * out_h * 6;
+    if (!use_ggx_octets(in_w, out_w, patch)) {
+        const uint32_t per = (n_out + n_shards - 1) / n_shards;
+        const uint32_t begin = shard * per < n_out ? shard * per : n_out;
+        const uint32_t count = per < n_out - begin ? per : n_out - begin;
+        return ibl_ggx_level_dev(d_env, in_w, in_h, out_w, out_h, mip_level, mip_levels, begin, count, d_out, stream);
+    }
+    const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
+    const uint32_t per = (n_oct + n_shards - 1) / n_shards;
+    const uint32_t begin = shard * per < n_oct ? shard * per : n_oct;
+    const uint32_t count = per < n_oct - begin ? per : n_oct - begin;
+    const uint32_t n_patches = 6 * (in_w / patch) * (in_h / patch);
+    g.last_counts[0] = (uint64_t)count * 8 * n_patches;
+    g.last_counts[1] = g.last_counts[2] = 0;
+    g.counts_pending = false;
+    if (count == 0) { g.timed_valid = false; return IBL_OK; }
+    return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, begin, count, 0, n_out, d_out, pick(stream));
 }
 
 int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,

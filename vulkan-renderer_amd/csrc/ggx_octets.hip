@@ -1,0 +1,417 @@
+// GGX specular prefilter (one mip level) through the cube's mirror symmetry (gfx950).
+//
+// Same quadrature as ggx.hip (integrateGGX, src/utilities/cube.cpp:152-309), evaluated
+// octet against octet.  Output texels, input texels and input patches all come in groups
+// of 8 mirror images (sign flips of x, y, z).  For an output octet with canonical
+// (all-positive) unit direction n and an input texel octet with canonical unit direction
+// u, the cosine between output member so and input member si depends only on the
+// component-wise sign product t = so (x) si:
+//     c_t = tx*nx*ux + ty*ny*uy + tz*nz*uz.
+// The GGX weight is a function of that cosine (times |w|^-3, which all 8 input members
+// share), and so is the reference's patch test (cube.cpp:256-258).  Hence, per (output
+// octet, input texel octet) and per sign pattern t that passes the patch test:
+// one cosine, ONE weight evaluation, then 8 x 4 FMAs that add it to the sums of the
+// 8 output members, each paired with input member so^t -- about 48 VALU instructions
+// for 8 texel pairs where the general kernel spends about 21 per pair.  The reference
+// computes each of those 8 cosines from the same operands in the same order, so
+// sharing them changes nothing it could see.
+//
+// Kernel plan
+//   ggx_oct_prep / ggx_oct_prep_patches   per level: one 7-float4 record per input texel
+//       octet (canonical unit direction, |w|^-3, radiance*|w|^-3 of the 8 members), stored
+//       patch-octet-major; canonical unit centre direction per patch octet.
+//   ggx_oct_pairs   grid = (blocks of 256 output octets in tile-major order) x (slices of
+//       patch octets).  Per 256 patch octets a bounding-cone test builds, in patch order,
+//       the list of (patch octet, candidate sign patterns); each candidate's records are
+//       staged in LDS; every lane runs the reference's exact float patch test for its own
+//       octet and each candidate pattern; a wave walks the records once and evaluates the
+//       patterns that pass for any of its lanes.  FP32 sums cover 64 records, then go to
+//       FP64 running sums.
+//   ggx_oct_final   per output octet: slices summed in order in FP64, divided, scattered
+//       to the member texels that lie in the requested (face, y, x) range.
+// A texel's value does not depend on the range or shard a call covers.
+#include "ibl_device.h"
+#include "ibl_kernels.h"
+#include <math.h>
+
+namespace ibl {
+
+constexpr int GO_THREADS = 256;
+constexpr int GO_REC = 7;              // float4 per texel-octet record
+constexpr int GO_PATCH_MAX = 256;      // records per patch octet (16 x 16)
+constexpr int GO_FLUSH = 64;           // records per FP32 chunk
+
+// Output octets are numbered tile-major: tiles of tw x tw canonical positions.
+__host__ __device__ inline uint32_t go_tile_edge(uint32_t hw) {
+    uint32_t tw = hw < 16 ? hw : 16;
+    while (hw % tw) tw--;
+    return tw;
+}
+
+__device__ __forceinline__ void go_decode(uint32_t g, uint32_t hw, uint32_t tw, uint32_t& axis, uint32_t& oj, uint32_t& oi) {
+    const uint32_t t2 = tw * tw, tpr = hw / tw;
+    const uint32_t tile = g / t2, within = g - tile * t2;
+    const uint32_t ly = within / tw, lx = within - ly * tw;
+    axis = tile / (tpr * tpr);
+    const uint32_t trem = tile - axis * (tpr * tpr);
+    const uint32_t ty = trem / tpr, tx = trem - ty * tpr;
+    oj = ty * tw + ly;
+    oi = tx * tw + lx;
+}
+
+__global__ __launch_bounds__(256) void ggx_oct_prep(const float4* __restrict__ env, uint32_t w, uint32_t ps,
+                                                     uint32_t n_rec, float4* __restrict__ rec) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rec) return;
+    const uint32_t ps2 = ps * ps, hpw = (w / ps) / 2;
+    const uint32_t po = k / ps2, sub = k - po * ps2;
+    const uint32_t sy = sub / ps, sx = sub - sy * ps;
+    const uint32_t axis = po / (hpw * hpw);
+    const uint32_t prem = po - axis * (hpw * hpw);
+    const uint32_t pj = prem / hpw, pi = prem - pj * hpw;
+    const uint32_t j = pj * ps + sy, i = pi * ps + sx;
+    Texel c = octet_member(axis, j, i, 0, w, w);
+    F3 d = ref_normal_from(c.face, c.x, c.y, w, w);     // all components > 0
+    F3 u = ref_normalize(d);
+    float l2 = ref_dot(d, d);
+    float s = 1.0f / (l2 * sqrtf(l2));
+    float v[28];
+    v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = s;
+#pragma unroll
+    for (uint32_t m = 0; m < 8; m++) {
+        Texel t = octet_member(axis, j, i, m, w, w);
+        float4 L = env[(t.face * w + t.y) * w + t.x];
+        v[4 + 3 * m] = L.x * s; v[5 + 3 * m] = L.y * s; v[6 + 3 * m] = L.z * s;
+    }
+#pragma unroll
+    for (int q = 0; q < GO_REC; q++)
+        rec[(size_t)k * GO_REC + q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+__global__ __launch_bounds__(256) void ggx_oct_prep_patches(uint32_t pw, uint32_t n_po, float4* __restrict__ pn) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_po) return;
+    const uint32_t hpw = pw / 2;
+    const uint32_t axis = p / (hpw * hpw);
+    const uint32_t rem = p - axis * (hpw * hpw);
+    const uint32_t pj = rem / hpw, pi = rem - pj * hpw;
+    Texel c = octet_member(axis, pj, pi, 0, pw, pw);
+    F3 u = ref_normalize(ref_normal_from(c.face, c.x, c.y, pw, pw));   // cube.cpp:198
+    pn[p] = make_float4(u.x, u.y, u.z, 0.0f);
+}
+
+struct GoConst {
+    float cutoff, om_a2, cmin;
+};
+
+// One sign pattern TAU of one record: weight from the cosine, added to all 8 members.
+template <int TAU, bool COUNT>
+__device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr, float a2p, const GoConst& k,
+                                        float (&acc)[8][4], uint32_t& n_acc) {
+    float u = fmaf(-0.5f, c, 0.5f);
+    float t = 1.0f - u;
+    float sq = __builtin_amdgcn_sqrtf(t);
+    float d = fmaf(u, k.om_a2, a2p);
+    float qd = (t - k.cutoff) * __builtin_amdgcn_rcpf(d);
+    float f = (c * sq) * (qd * qd);
+    bool ok = c > thr;
+    f = ok ? f : 0.0f;
+    if (COUNT) n_acc += ok ? 1u : 0u;
+    const float fs = f * r[3];
+#pragma unroll
+    for (int so = 0; so < 8; so++) {
+        const int si = so ^ TAU;
+        acc[so][0] += fs;
+        acc[so][1] = fmaf(f, r[4 + 3 * si], acc[so][1]);
+        acc[so][2] = fmaf(f, r[5 + 3 * si], acc[so][2]);
+        acc[so][3] = fmaf(f, r[6 + 3 * si], acc[so][3]);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
+    const float4* __restrict__ rec, const float4* __restrict__ pn,
+    uint32_t n_po, uint32_t po_per_slice, uint32_t ps2,
+    uint32_t out_w, uint32_t tw, uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+    float cutoff, float a2m1, float cmin, float theta_acc,
+    double* __restrict__ partial, unsigned long long* __restrict__ counts) {
+    __shared__ float4 s_rec[GO_PATCH_MAX * GO_REC];
+    __shared__ uint32_t s_list[GO_THREADS];
+    __shared__ uint32_t s_lmask[GO_THREADS];
+    __shared__ float s_red[4][GO_THREADS / 64];
+    __shared__ uint32_t s_wcnt[GO_THREADS / 64];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t lo = blockIdx.x * GO_THREADS + tid;
+    const bool lane_valid = lo < oct_count;
+    const uint32_t hw = out_w / 2;
+    uint32_t axis, oj, oi;
+    go_decode(oct_begin + min(lo, oct_count - 1), hw, tw, axis, oj, oi);
+
+    // members of this octet inside the requested (face, y, x) range
+    uint32_t member_mask = 0;
+    if (lane_valid) {
+#pragma unroll
+        for (uint32_t m = 0; m < 8; m++) {
+            Texel t = octet_member(axis, oj, oi, m, out_w, out_w);
+            uint32_t o = (t.face * out_w + t.y) * out_w + t.x;
+            if (o - out_begin < out_count) member_mask |= 1u << m;
+        }
+    }
+    const bool active = member_mask != 0u;
+    if (!__syncthreads_or(active)) return;
+
+    Texel c0 = octet_member(axis, oj, oi, 0, out_w, out_w);
+    const F3 n = ref_normalize(ref_normal_from(c0.face, c0.x, c0.y, out_w, out_w));   // cube.cpp:242
+    GoConst kc;
+    kc.cutoff = cutoff; kc.om_a2 = -a2m1; kc.cmin = cmin;
+    float a2p;
+    {
+        double eps = ((double)n.x * n.x + (double)n.y * n.y + (double)n.z * n.z) - 1.0;
+        a2p = (float)((1.0 + (double)a2m1) - (double)kc.om_a2 * 0.75 * eps);
+    }
+
+    // Bounding cone of the block's active canonical directions.
+    float sumx = active ? n.x : 0.f, sumy = active ? n.y : 0.f, sumz = active ? n.z : 0.f;
+    for (int off = 32; off > 0; off >>= 1) {
+        sumx += __shfl_xor(sumx, off); sumy += __shfl_xor(sumy, off); sumz += __shfl_xor(sumz, off);
+    }
+    if (lane == 0) { s_red[0][wave] = sumx; s_red[1][wave] = sumy; s_red[2][wave] = sumz; }
+    __syncthreads();
+    float axx = 0.f, axy = 0.f, axz = 0.f;
+    for (int w = 0; w < GO_THREADS / 64; w++) { axx += s_red[0][w]; axy += s_red[1][w]; axz += s_red[2][w]; }
+    {
+        float inv = rsqrtf(axx * axx + axy * axy + axz * axz);
+        axx *= inv; axy *= inv; axz *= inv;
+    }
+    float cmin_dot = active ? (axx * n.x + axy * n.y + axz * n.z) : 1.0f;
+    for (int off = 32; off > 0; off >>= 1) cmin_dot = fminf(cmin_dot, __shfl_xor(cmin_dot, off));
+    if (lane == 0) s_red[3][wave] = cmin_dot;
+    __syncthreads();
+    for (int w = 0; w < GO_THREADS / 64; w++) cmin_dot = fminf(cmin_dot, s_red[3][w]);
+    float block_thr;
+    {
+        float ang = theta_acc + acosf(fminf(fmaxf(cmin_dot, -1.0f), 1.0f)) + 4e-3f;
+        block_thr = ang >= 3.14159f ? -2.0f : cosf(ang);
+    }
+
+    float acc[8][4];
+    double dacc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { acc[m][k] = 0.0f; dacc[m][k] = 0.0; }
+    uint32_t n_tested = 0, n_accepted = 0;
+    unsigned long long tot_tested = 0, tot_accepted = 0;
+
+    const uint32_t p0 = blockIdx.y * po_per_slice;
+    const uint32_t p1 = min(n_po, p0 + po_per_slice);
+
+    for (uint32_t base = p0; base < p1; base += GO_THREADS) {
+        // ---- candidates of this chunk: (patch octet, sign patterns), in patch order --
+        const uint32_t q = base + tid;
+        uint32_t cmask = 0;
+        if (q < p1) {
+            const float4 c4 = pn[q];
+            const float a = c4.x * axx, b = c4.y * axy, c = c4.z * axz;
+#pragma unroll
+            for (int tau = 0; tau < 8; tau++) {
+                float dsum = ((tau & 1) ? -a : a) + ((tau & 2) ? -b : b) + ((tau & 4) ? -c : c);
+                if (dsum >= block_thr) cmask |= 1u << tau;
+            }
+        }
+        const bool cand = cmask != 0u;
+        const unsigned long long bal = __ballot(cand);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        uint32_t offs = 0, n_cand = 0;
+        for (uint32_t w = 0; w < GO_THREADS / 64; w++) {
+            const uint32_t cw = s_wcnt[w];
+            if (w < wave) offs += cw;
+            n_cand += cw;
+        }
+        if (cand) {
+            const uint32_t pos = offs + __popcll(bal & ((1ull << lane) - 1ull));
+            s_list[pos] = q;
+            s_lmask[pos] = cmask;
+        }
+        __syncthreads();
+
+        for (uint32_t ci = 0; ci < n_cand; ci++) {
+            const uint32_t po = s_list[ci];
+            const uint32_t pmask = s_lmask[ci];
+            // stage the patch octet's records
+            {
+                const size_t gbase = (size_t)po * ps2 * GO_REC;
+                const uint32_t total = ps2 * GO_REC;
+                for (uint32_t idx = tid; idx < total; idx += GO_THREADS) s_rec[idx] = rec[gbase + idx];
+            }
+            // exact per-lane patch tests (cube.cpp:256-258), one per candidate pattern
+            const float4 c4 = pn[po];
+            float thr[8];
+            uint32_t lane_pass = 0;
+#pragma unroll
+            for (int tau = 0; tau < 8; tau++) {
+                bool pass = false;
+                if (pmask & (1u << tau)) {    // wave-uniform
+                    F3 pc = { (tau & 1) ? -c4.x : c4.x, (tau & 2) ? -c4.y : c4.y, (tau & 4) ? -c4.z : c4.z };
+                    pass = active && ref_cone_test(pc, n, cutoff);
+                }
+                thr[tau] = pass ? cmin : 2.0f;
+                lane_pass |= pass ? (1u << tau) : 0u;
+            }
+            if (COUNT) n_tested += __popc(lane_pass) * ps2 * 8u;
+            // patterns that pass for any lane of this wave
+            uint32_t wmask = 0;
+#pragma unroll
+            for (int tau = 0; tau < 8; tau++)
+                if (__any((lane_pass >> tau) & 1u)) wmask |= 1u << tau;
+            __syncthreads();
+            if (wmask != 0u) {
+                for (uint32_t e0 = 0; e0 < ps2; e0 += GO_FLUSH) {
+                    const uint32_t e1 = min(ps2, e0 + GO_FLUSH);
+                    if (wmask == 1u) {
+                        for (uint32_t e = e0; e < e1; e++) {
+                            float r[28];
+#pragma unroll
+                            for (int qq = 0; qq < GO_REC; qq++) {
+                                const float4 t4 = s_rec[e * GO_REC + qq];
+                                r[4 * qq] = t4.x; r[4 * qq + 1] = t4.y; r[4 * qq + 2] = t4.z; r[4 * qq + 3] = t4.w;
+                            }
+                            float c = n.x * r[0];
+                            c = fmaf(n.y, r[1], c);
+                            c = fmaf(n.z, r[2], c);
+                            go_body<0, COUNT>(c, r, thr[0], a2p, kc, acc, n_accepted);
+                        }
+                    } else {
+                        for (uint32_t e = e0; e < e1; e++) {
+                            float r[28];
+#pragma unroll
+                            for (int qq = 0; qq < GO_REC; qq++) {
+                                const float4 t4 = s_rec[e * GO_REC + qq];
+                                r[4 * qq] = t4.x; r[4 * qq + 1] = t4.y; r[4 * qq + 2] = t4.z; r[4 * qq + 3] = t4.w;
+                            }
+                            const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
+                            const float s1 = a + b, s2 = a - b;
+                            if (wmask & 1u)   go_body<0, COUNT>(s1 + cc, r, thr[0], a2p, kc, acc, n_accepted);
+                            if (wmask & 2u)   go_body<1, COUNT>(cc - s2, r, thr[1], a2p, kc, acc, n_accepted);
+                            if (wmask & 4u)   go_body<2, COUNT>(s2 + cc, r, thr[2], a2p, kc, acc, n_accepted);
+                            if (wmask & 8u)   go_body<3, COUNT>(cc - s1, r, thr[3], a2p, kc, acc, n_accepted);
+                            if (wmask & 16u)  go_body<4, COUNT>(s1 - cc, r, thr[4], a2p, kc, acc, n_accepted);
+                            if (wmask & 32u)  go_body<5, COUNT>(-s2 - cc, r, thr[5], a2p, kc, acc, n_accepted);
+                            if (wmask & 64u)  go_body<6, COUNT>(s2 - cc, r, thr[6], a2p, kc, acc, n_accepted);
+                            if (wmask & 128u) go_body<7, COUNT>(-s1 - cc, r, thr[7], a2p, kc, acc, n_accepted);
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < 8; m++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { dacc[m][k] += (double)acc[m][k]; acc[m][k] = 0.0f; }
+                }
+            }
+            __syncthreads();
+        }
+        if (COUNT) {
+            tot_tested += n_tested; tot_accepted += (unsigned long long)n_accepted * 8ull;
+            n_tested = 0; n_accepted = 0;
+        }
+    }
+
+    if (lane_valid) {
+#pragma unroll
+        for (int m = 0; m < 8; m++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                partial[((size_t)blockIdx.y * 32 + (m * 4 + k)) * oct_count + lo] = dacc[m][k];
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) {
+            tot_tested += __shfl_xor(tot_tested, off);
+            tot_accepted += __shfl_xor(tot_accepted, off);
+        }
+        if (lane == 0) { atomicAdd(&counts[1], tot_tested); atomicAdd(&counts[2], tot_accepted); }
+    }
+}
+
+__global__ __launch_bounds__(256) void ggx_oct_final(const double* __restrict__ partial, uint32_t n_slices,
+                                                      uint32_t out_w, uint32_t tw, uint32_t oct_begin, uint32_t oct_count,
+                                                      uint32_t out_begin, uint32_t out_count, float4* __restrict__ out) {
+    uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lo >= oct_count) return;
+    uint32_t axis, oj, oi;
+    go_decode(oct_begin + lo, out_w / 2, tw, axis, oj, oi);
+    for (uint32_t m = 0; m < 8; m++) {
+        Texel t = octet_member(axis, oj, oi, m, out_w, out_w);
+        uint32_t o = (t.face * out_w + t.y) * out_w + t.x;
+        if (o - out_begin >= out_count) continue;
+        double v[4];
+        for (uint32_t k = 0; k < 4; k++) {
+            double sum = 0.0;
+            for (uint32_t sl = 0; sl < n_slices; sl++) sum += partial[((size_t)sl * 32 + (m * 4 + k)) * oct_count + lo];
+            v[k] = sum;
+        }
+        double inv = 1.0 / v[0];   // cube.cpp:305 via linear.hpp:93-95
+        out[o] = make_float4((float)(inv * v[1]), (float)(inv * v[2]), (float)(inv * v[3]), 0.0f);
+    }
+}
+
+// ---- launch plan -----------------------------------------------------------
+
+bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch) {
+    if (patch == 0 || in_w % patch) return false;
+    const uint32_t pw = in_w / patch;
+    return cube_is_mirror_exact(in_w) && cube_is_mirror_exact(out_w) && cube_is_mirror_exact(pw);
+}
+
+GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t oct_count) {
+    GgxOctPlan pl;
+    pl.lv = ggx_level_params(mip, mips, in_w, in_w);
+    const uint32_t ps = pl.lv.patch, pw = in_w / ps;
+    pl.n_po = 3 * (pw / 2) * (pw / 2);
+    pl.tw = go_tile_edge(out_w / 2);
+    // slices come from the level geometry only (range/shard independence)
+    const uint32_t n_oct_level = 3 * (out_w / 2) * (out_w / 2);
+    const uint32_t blocks_level = (n_oct_level + GO_THREADS - 1) / GO_THREADS;
+    uint32_t want = (1024 + blocks_level - 1) / blocks_level;
+    uint32_t max_slices = (pl.n_po + 3) / 4;                 // >= 4 patch octets per slice
+    if (max_slices == 0) max_slices = 1;
+    uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
+    pl.po_per_slice = (pl.n_po + slices - 1) / slices;
+    pl.n_slices = (pl.n_po + pl.po_per_slice - 1) / pl.po_per_slice;
+    pl.out_blocks = (oct_count + GO_THREADS - 1) / GO_THREADS;
+    pl.partial_bytes = (size_t)pl.n_slices * 32 * oct_count * sizeof(double);
+    pl.rec_bytes = (size_t)pl.n_po * ps * ps * GO_REC * sizeof(float4);
+    pl.pn_bytes = (size_t)pl.n_po * sizeof(float4);
+    return pl;
+}
+
+hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_w,
+                          uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+                          float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
+                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const uint32_t ps = pl.lv.patch, ps2 = ps * ps, pw = in_w / ps;
+    const uint32_t n_rec = pl.n_po * ps2;
+    ggx_oct_prep<<<(n_rec + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, ps, n_rec, (float4*)d_rec);
+    ggx_oct_prep_patches<<<(pl.n_po + 255) / 256, 256, 0, stream>>>(pw, pl.n_po, (float4*)d_pn);
+    const double cut = (double)pl.lv.cutoff;
+    const float cmin = (float)fmax(0.0, 2.0 * cut - 1.0);
+    const float theta_acc = (float)acos(fmin(1.0, fmax(-1.0, 2.0 * cut - 1.0)));
+    const float a2m1 = pl.lv.alpha2 - 1.0f;
+    dim3 grid(pl.out_blocks, pl.n_slices);
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    if (d_counts)
+        ggx_oct_pairs<true><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
+            pl.po_per_slice, ps2, out_w, pl.tw, oct_begin, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
+            theta_acc, d_partial, d_counts);
+    else
+        ggx_oct_pairs<false><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
+            pl.po_per_slice, ps2, out_w, pl.tw, oct_begin, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
+            theta_acc, d_partial, d_counts);
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    ggx_oct_final<<<(oct_count + 255) / 256, 256, 0, stream>>>(d_partial, pl.n_slices, out_w, pl.tw, oct_begin,
+                                                               oct_count, out_begin, out_count, (float4*)d_out);
+    return hipGetLastError();
+}
+
+}  // namespace ibl

@@ -65,6 +65,25 @@ hipError_t ggx_launch(const GgxPlan& pl, const float* d_env, uint32_t in_w, uint
                       void* d_a, void* d_b, void* d_pn, double* d_partial, unsigned long long* d_counts,
                       hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
+// Mirror-octet form of the GGX level (ggx_octets.hip).
+struct GgxOctPlan {
+    GgxLevel lv;
+    uint32_t n_po;            // patch octets: 3 * (pw/2)^2
+    uint32_t tw;              // edge of the output tile used for octet numbering
+    uint32_t po_per_slice;
+    uint32_t n_slices;
+    uint32_t out_blocks;
+    size_t partial_bytes;     // [slice][32][oct_count] double
+    size_t rec_bytes;         // 7 float4 per input texel octet
+    size_t pn_bytes;          // float4 per patch octet
+};
+bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
+GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t oct_count);
+hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_w,
+                          uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+                          float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
+                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+
 hipError_t brdf_lut_launch(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int mode,
                            uint32_t cell_begin, uint32_t cell_count, float* d_out, hipStream_t stream,
                            hipEvent_t ev0, hipEvent_t ev1);
