@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c4", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c4", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -85,8 +85,8 @@ class Workload:
             self.desc = ("C%s: Lambertian irradiance %dx%d/face -> %dx%d/face, all (output, input) texel pairs"
                          % (name[1], self.in_w, self.in_w, self.out_w, self.out_w))
             self.bytes_per_launch = 24 * self.n_in + 16 * self.count
-        elif name == "c3":
-            self.in_w, self.min_size = 512, 16
+        elif name in ("c3", "c5"):
+            self.in_w, self.min_size = (512, 16) if name == "c3" else (2048, 16)
             strip = vra.synth.hdr_environment(self.in_w, seed=args.seed)
             rgbe = t.from_numpy(strip).to(ibl.device)
             self.env = ibl.rgbe_decode(rgbe).reshape(6, self.in_w, self.in_w, 4).contiguous()
@@ -115,9 +115,18 @@ class Workload:
             self.flop_per_launch = frac * (FLOP_PER_GGX_ACCEPTED * lv1["accepted"]
                                            + FLOP_PER_GGX_REJECTED * (lv1["tested"] - lv1["accepted"]))
             self.kernel = "ggx_oct_pairs (level 1)"
-            self.desc = ("C3: GGX prefilter chain of a 512x512/face environment, %d levels, --input-downscale 1; "
-                         "samples = in-patch texel tests (%.3g tested, %.3g accepted)" % (self.mips, tested, accepted))
+            self.desc = ("C%s: GGX prefilter chain of a %dx%d/face environment, %d levels, --input-downscale 1; "
+                         "samples = in-patch texel tests (%.3g tested, %.3g accepted)"
+                         % (name[1], self.in_w, self.in_w, self.mips, tested, accepted))
             self.bytes_per_launch = 32 * 6 * self.in_w * self.in_w + 16 * lv1["count"]
+            if name == "c5":
+                # plus the Lambertian irradiance of the 1024x1024/face (2x box-filtered) environment
+                self.lam_env = ibl.downscale(self.env, 2)
+                self.lam_w = 128
+                self.lam_out = t.zeros((6, self.lam_w, self.lam_w, 4), dtype=t.float32, device=ibl.device)
+                pairs = 6 * self.lam_w * self.lam_w * 6 * 1024 * 1024
+                self.samples += pairs
+                self.desc += "; + Lambertian 1024x1024/face -> 128x128/face (%.3g pairs)" % pairs
         elif name == "c2":
             self.s = 32
             self.n_cells = 256 * 256
@@ -139,7 +148,13 @@ class Workload:
             self.kernel_ms.append(ibl.last_kernel_ms() if self.count else 0.0)
             if self.world > 1:
                 d.all_reduce(self.out)
-        elif self.name == "c3":
+        elif self.name in ("c3", "c5"):
+            if self.name == "c5":
+                if self.world > 1:
+                    self.lam_out.zero_()
+                ibl.lambertian_shard(self.lam_env, self.lam_w, self.rank, self.world, out=self.lam_out)
+                if self.world > 1:
+                    d.all_reduce(self.lam_out)
             for lv in self.levels:
                 if self.world > 1:
                     lv["out"].zero_()
@@ -177,7 +192,7 @@ def cpu_baseline(wl, target_seconds):
         want = want.reshape(-1, 4)[begin:begin + count]
         units = count * wl.n_in
         sample = "%d of %d output texels (range %d..%d) x all %d input texels" % (count, n_out, begin, begin + count, wl.n_in)
-    elif wl.name == "c3":
+    elif wl.name in ("c3", "c5"):
         lv = wl.levels[1]          # level 2: representative cost, full hemisphere
         n_out = lv["n_out"]
         pilot = min(n_out, 32 * ncores)

@@ -183,6 +183,17 @@ int ibl_last_kernel_ms(float* ms) {
     return IBL_OK;
 }
 
+// Diagnostic (not part of the ABI): raw device counter `idx` of the last counted call.
+int ibl_debug_counter(int idx, uint64_t* value) {
+    if (int rc = check_ready()) return rc;
+    if (!g.counts.ptr || idx < 0 || idx > 3 || !value) return fail(IBL_EINVAL, "no counters");
+    unsigned long long h[4];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h, g.counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
+    *value = h[idx];
+    return IBL_OK;
+}
+
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
     if (int rc = check_ready()) return rc;
     if (g.counts_pending) {
@@ -305,18 +316,19 @@ int ggx_counts_buffer(hipStream_t s, unsigned long long** d_counts) {
     return IBL_OK;
 }
 
-// Octet kernel over output octets [oct_begin, oct_begin+oct_count), writing the member
-// texels inside [out_begin, out_begin+out_count).
+// Octet kernel over the 256-octet blocks first_block, first_block + block_stride, ...,
+// writing the member texels inside [out_begin, out_begin+out_count).
 int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
-                   uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count, float* d_out,
+                   uint32_t first_block, uint32_t block_stride, uint32_t out_begin, uint32_t out_count, float* d_out,
                    hipStream_t s) {
-    ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, oct_count);
+    ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, first_block, block_stride);
+    if (pl.out_blocks == 0) { g.timed_valid = false; return IBL_OK; }
     if (int rc = ensure(g.a, pl.rec_bytes)) return rc;
     if (int rc = ensure(g.pn, pl.pn_bytes)) return rc;
     if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
     unsigned long long* d_counts = nullptr;
     if (int rc = ggx_counts_buffer(s, &d_counts)) return rc;
-    HIP_TRY(ibl::ggx_oct_launch(pl, d_env, in_w, out_w, oct_begin, oct_count, out_begin, out_count, d_out, g.a.ptr,
+    HIP_TRY(ibl::ggx_oct_launch(pl, d_env, in_w, out_w, first_block, block_stride, out_begin, out_count, d_out, g.a.ptr,
                                 g.pn.ptr, (double*)g.partial.ptr, d_counts, s, g.timing ? g.ev0 : nullptr,
                                 g.timing ? g.ev1 : nullptr));
     g.timed_valid = g.timing;
@@ -341,8 +353,7 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
     if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
     hipStream_t s = pick(stream);
     if (use_ggx_octets(in_w, out_w, patch)) {
-        const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
-        return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, 0, n_oct, out_begin, out_count, d_out, s);
+        return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, 0, 1, out_begin, out_count, d_out, s);
     }
     ibl::GgxPlan pl = ibl::ggx_plan(in_w, in_h, out_w, out_h, mip_level, mip_levels, out_count);
     if (int rc = ensure(g.a, pl.prep_bytes_a)) return rc;
@@ -373,16 +384,17 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
         const uint32_t count = per < n_out - begin ? per : n_out - begin;
         return ibl_ggx_level_dev(d_env, in_w, in_h, out_w, out_h, mip_level, mip_levels, begin, count, d_out, stream);
     }
-    const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
-    const uint32_t per = (n_oct + n_shards - 1) / n_shards;
-    const uint32_t begin = shard * per < n_oct ? shard * per : n_oct;
-    const uint32_t count = per < n_oct - begin ? per : n_oct - begin;
+    // GGX cost per output tile varies over the cube (patches near a face centre subtend
+    // more solid angle), so shards take every n_shards-th block of 256 octets.
     const uint32_t n_patches = 6 * (in_w / patch) * (in_h / patch);
-    g.last_counts[0] = (uint64_t)count * 8 * n_patches;
+    const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
+    const uint32_t n_blocks = (n_oct + 255) / 256;
+    const uint32_t mine = shard < n_blocks ? (n_blocks - shard + n_shards - 1) / n_shards : 0;
+    g.last_counts[0] = (uint64_t)mine * 256 * 8 * n_patches;
     g.last_counts[1] = g.last_counts[2] = 0;
     g.counts_pending = false;
-    if (count == 0) { g.timed_valid = false; return IBL_OK; }
-    return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, begin, count, 0, n_out, d_out, pick(stream));
+    if (mine == 0) { g.timed_valid = false; return IBL_OK; }
+    return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, shard, n_shards, 0, n_out, d_out, pick(stream));
 }
 
 int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,

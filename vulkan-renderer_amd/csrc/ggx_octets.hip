@@ -132,7 +132,8 @@ template <bool COUNT>
 __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn,
     uint32_t n_po, uint32_t po_per_slice, uint32_t ps2,
-    uint32_t out_w, uint32_t tw, uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+    uint32_t out_w, uint32_t tw, uint32_t first_block, uint32_t block_stride, uint32_t n_oct, uint32_t oct_local,
+    uint32_t out_begin, uint32_t out_count,
     float cutoff, float a2m1, float cmin, float theta_acc,
     double* __restrict__ partial, unsigned long long* __restrict__ counts) {
     __shared__ float4 s_rec[GO_PATCH_MAX * GO_REC];
@@ -143,11 +144,15 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
+    // This call owns the 256-octet blocks first_block, first_block + block_stride, ...
+    // of the tile-major octet order; lo indexes its partial sums.
     const uint32_t lo = blockIdx.x * GO_THREADS + tid;
-    const bool lane_valid = lo < oct_count;
+    const uint32_t gidx = (blockIdx.x * block_stride + first_block) * GO_THREADS + tid;
+    const bool lane_valid = gidx < n_oct;
+    const uint32_t oct_count = oct_local;
     const uint32_t hw = out_w / 2;
     uint32_t axis, oj, oi;
-    go_decode(oct_begin + min(lo, oct_count - 1), hw, tw, axis, oj, oi);
+    go_decode(min(gidx, n_oct - 1), hw, tw, axis, oj, oi);
 
     // members of this octet inside the requested (face, y, x) range
     uint32_t member_mask = 0;
@@ -205,14 +210,18 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
     uint32_t n_tested = 0, n_accepted = 0;
     unsigned long long tot_tested = 0, tot_accepted = 0;
 
-    const uint32_t p0 = blockIdx.y * po_per_slice;
-    const uint32_t p1 = min(n_po, p0 + po_per_slice);
+    // Slices interleave the patch octets (slice s owns q = s, s + S, s + 2S, ...), so
+    // every slice sees every region of the sphere and the workgroups of one output
+    // tile carry equal shares of its cone.
+    const uint32_t n_slices = gridDim.y;
+    const uint32_t my_count = (n_po + n_slices - 1 - blockIdx.y) / n_slices;   // patch octets of this slice
 
-    for (uint32_t base = p0; base < p1; base += GO_THREADS) {
+    for (uint32_t base = 0; base < my_count; base += GO_THREADS) {
         // ---- candidates of this chunk: (patch octet, sign patterns), in patch order --
-        const uint32_t q = base + tid;
+        const uint32_t qi = base + tid;
+        const uint32_t q = qi * n_slices + blockIdx.y;
         uint32_t cmask = 0;
-        if (q < p1) {
+        if (qi < my_count) {
             const float4 c4 = pn[q];
             const float a = c4.x * axx, b = c4.y * axy, c = c4.z * axz;
 #pragma unroll
@@ -262,6 +271,12 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
                 lane_pass |= pass ? (1u << tau) : 0u;
             }
             if (COUNT) n_tested += __popc(lane_pass) * ps2 * 8u;
+            if (COUNT && lane == 0) {
+                // diagnostic: lane slots the wave spends (64 lanes per executed pattern)
+                uint32_t wm = 0;
+                for (int tau = 0; tau < 8; tau++) if (__any((lane_pass >> tau) & 1u)) wm++;
+                atomicAdd(&counts[3], (unsigned long long)wm * ps2 * 8ull * 64ull);
+            }
             // patterns that pass for any lane of this wave
             uint32_t wmask = 0;
 #pragma unroll
@@ -335,12 +350,14 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
 }
 
 __global__ __launch_bounds__(256) void ggx_oct_final(const double* __restrict__ partial, uint32_t n_slices,
-                                                      uint32_t out_w, uint32_t tw, uint32_t oct_begin, uint32_t oct_count,
+                                                      uint32_t out_w, uint32_t tw, uint32_t first_block,
+                                                      uint32_t block_stride, uint32_t n_oct, uint32_t oct_count,
                                                       uint32_t out_begin, uint32_t out_count, float4* __restrict__ out) {
-    uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lo >= oct_count) return;
+    const uint32_t lo = blockIdx.x * GO_THREADS + threadIdx.x;
+    const uint32_t gidx = (blockIdx.x * block_stride + first_block) * GO_THREADS + threadIdx.x;
+    if (gidx >= n_oct) return;
     uint32_t axis, oj, oi;
-    go_decode(oct_begin + lo, out_w / 2, tw, axis, oj, oi);
+    go_decode(gidx, out_w / 2, tw, axis, oj, oi);
     for (uint32_t m = 0; m < 8; m++) {
         Texel t = octet_member(axis, oj, oi, m, out_w, out_w);
         uint32_t o = (t.face * out_w + t.y) * out_w + t.x;
@@ -364,7 +381,8 @@ bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch) {
     return cube_is_mirror_exact(in_w) && cube_is_mirror_exact(out_w) && cube_is_mirror_exact(pw);
 }
 
-GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t oct_count) {
+GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t first_block,
+                        uint32_t block_stride) {
     GgxOctPlan pl;
     pl.lv = ggx_level_params(mip, mips, in_w, in_w);
     const uint32_t ps = pl.lv.patch, pw = in_w / ps;
@@ -373,13 +391,15 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     // slices come from the level geometry only (range/shard independence)
     const uint32_t n_oct_level = 3 * (out_w / 2) * (out_w / 2);
     const uint32_t blocks_level = (n_oct_level + GO_THREADS - 1) / GO_THREADS;
-    uint32_t want = (1024 + blocks_level - 1) / blocks_level;
-    uint32_t max_slices = (pl.n_po + 3) / 4;                 // >= 4 patch octets per slice
+    uint32_t want = (3072 + blocks_level - 1) / blocks_level;
+    uint32_t max_slices = pl.n_po;                           // at least one patch octet per slice
     if (max_slices == 0) max_slices = 1;
     uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
     pl.po_per_slice = (pl.n_po + slices - 1) / slices;
-    pl.n_slices = (pl.n_po + pl.po_per_slice - 1) / pl.po_per_slice;
-    pl.out_blocks = (oct_count + GO_THREADS - 1) / GO_THREADS;
+    pl.n_slices = slices;
+    // blocks first_block, first_block + stride, ... below blocks_level
+    pl.out_blocks = first_block < blocks_level ? (blocks_level - first_block + block_stride - 1) / block_stride : 0;
+    const uint32_t oct_count = pl.out_blocks * GO_THREADS;
     pl.partial_bytes = (size_t)pl.n_slices * 32 * oct_count * sizeof(double);
     pl.rec_bytes = (size_t)pl.n_po * ps * ps * GO_REC * sizeof(float4);
     pl.pn_bytes = (size_t)pl.n_po * sizeof(float4);
@@ -387,7 +407,7 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
 }
 
 hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_w,
-                          uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+                          uint32_t first_block, uint32_t block_stride, uint32_t out_begin, uint32_t out_count,
                           float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
                           hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t ps = pl.lv.patch, ps2 = ps * ps, pw = in_w / ps;
@@ -399,18 +419,21 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const float theta_acc = (float)acos(fmin(1.0, fmax(-1.0, 2.0 * cut - 1.0)));
     const float a2m1 = pl.lv.alpha2 - 1.0f;
     dim3 grid(pl.out_blocks, pl.n_slices);
+    const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
+    const uint32_t oct_count = pl.out_blocks * GO_THREADS;
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (d_counts)
         ggx_oct_pairs<true><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
-            pl.po_per_slice, ps2, out_w, pl.tw, oct_begin, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
+            pl.po_per_slice, ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, d_partial, d_counts);
     else
         ggx_oct_pairs<false><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
-            pl.po_per_slice, ps2, out_w, pl.tw, oct_begin, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
+            pl.po_per_slice, ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, d_partial, d_counts);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    ggx_oct_final<<<(oct_count + 255) / 256, 256, 0, stream>>>(d_partial, pl.n_slices, out_w, pl.tw, oct_begin,
-                                                               oct_count, out_begin, out_count, (float4*)d_out);
+    ggx_oct_final<<<pl.out_blocks, GO_THREADS, 0, stream>>>(d_partial, pl.n_slices, out_w, pl.tw, first_block,
+                                                            block_stride, n_oct, oct_count, out_begin, out_count,
+                                                            (float4*)d_out);
     return hipGetLastError();
 }
 

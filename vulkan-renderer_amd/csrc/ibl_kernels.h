@@ -73,14 +73,16 @@ struct GgxOctPlan {
     uint32_t po_per_slice;
     uint32_t n_slices;
     uint32_t out_blocks;
-    size_t partial_bytes;     // [slice][32][oct_count] double
+    size_t partial_bytes;     // [slice][32][out_blocks*256] double
     size_t rec_bytes;         // 7 float4 per input texel octet
     size_t pn_bytes;          // float4 per patch octet
 };
 bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
-GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t oct_count);
+// The call covers the 256-octet blocks first_block, first_block + block_stride, ...
+GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t first_block,
+                        uint32_t block_stride);
 hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_w,
-                          uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+                          uint32_t first_block, uint32_t block_stride, uint32_t out_begin, uint32_t out_count,
                           float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
                           hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
