@@ -20,13 +20,14 @@
 //   ggx_oct_prep / ggx_oct_prep_patches   per level: one 7-float4 record per input texel
 //       octet (canonical unit direction, |w|^-3, radiance*|w|^-3 of the 8 members), stored
 //       patch-octet-major; canonical unit centre direction per patch octet.
-//   ggx_oct_pairs   grid = (blocks of 256 output octets in tile-major order) x (slices of
-//       patch octets).  Per 256 patch octets a bounding-cone test builds, in patch order,
-//       the list of (patch octet, candidate sign patterns); each candidate's records are
-//       staged in LDS; every lane runs the reference's exact float patch test for its own
-//       octet and each candidate pattern; a wave walks the records once and evaluates the
-//       patterns that pass for any of its lanes.  FP32 sums cover 64 records, then go to
-//       FP64 running sums.
+//   ggx_oct_pairs   grid = (blocks of 256 output octets in tile-major order) x (interleaved
+//       slices of patch octets); every wave of 64 octets works alone.  Per 64 patch octets a
+//       bounding-cone test marks, per lane, the candidate (patch octet, sign patterns); the
+//       wave visits the candidates in patch order (ballot + readlane); every lane runs the
+//       reference's exact float patch test for its own octet and each candidate pattern; the
+//       wave walks the patch's records once, reading them with wave-uniform (scalar) loads,
+//       and evaluates the patterns that pass for any of its lanes.  FP32 sums cover 64
+//       records, then go to FP64 running sums.  No LDS, no barriers.
 //   ggx_oct_final   per output octet: slices summed in order in FP64, divided, scattered
 //       to the member texels that lie in the requested (face, y, x) range.
 // A texel's value does not depend on the range or shard a call covers.
@@ -38,8 +39,7 @@ namespace ibl {
 
 constexpr int GO_THREADS = 256;
 constexpr int GO_REC = 7;              // float4 per texel-octet record
-constexpr int GO_PATCH_MAX = 256;      // records per patch octet (16 x 16)
-constexpr int GO_FLUSH = 64;           // records per FP32 chunk
+constexpr int GO_FLUSH = 64;           // records per FP32 chunk when all 8 patterns are live
 
 // Output octets are numbered tile-major: tiles of tw x tw canonical positions.
 __host__ __device__ inline uint32_t go_tile_edge(uint32_t hw) {
@@ -128,22 +128,24 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
     }
 }
 
+// Every wave works alone: 64 output octets, its own bounding cone, its own walk over
+// the slice's patch octets.  Nothing is staged in LDS and there is no barrier: the
+// records of a candidate patch octet are the same for all 64 lanes, so they are read
+// with wave-uniform addresses (scalar loads through the scalar data cache) and feed
+// the VALU as scalar operands.
+#ifndef GO_MIN_WAVES
+#define GO_MIN_WAVES 4   // 128 registers: a few spills, but 4 waves per SIMD measured faster than 3
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
+__global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn,
     uint32_t n_po, uint32_t po_per_slice, uint32_t ps2,
     uint32_t out_w, uint32_t tw, uint32_t first_block, uint32_t block_stride, uint32_t n_oct, uint32_t oct_local,
     uint32_t out_begin, uint32_t out_count,
     float cutoff, float a2m1, float cmin, float theta_acc,
     double* __restrict__ partial, unsigned long long* __restrict__ counts) {
-    __shared__ float4 s_rec[GO_PATCH_MAX * GO_REC];
-    __shared__ uint32_t s_list[GO_THREADS];
-    __shared__ uint32_t s_lmask[GO_THREADS];
-    __shared__ float s_red[4][GO_THREADS / 64];
-    __shared__ uint32_t s_wcnt[GO_THREADS / 64];
-
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t lane = tid & 63;
     // This call owns the 256-octet blocks first_block, first_block + block_stride, ...
     // of the tile-major octet order; lo indexes its partial sums.
     const uint32_t lo = blockIdx.x * GO_THREADS + tid;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
         }
     }
     const bool active = member_mask != 0u;
-    if (!__syncthreads_or(active)) return;
+    if (!__any(active)) return;      // no barrier anywhere below: a wave may leave alone
 
     Texel c0 = octet_member(axis, oj, oi, 0, out_w, out_w);
     const F3 n = ref_normalize(ref_normal_from(c0.face, c0.x, c0.y, out_w, out_w));   // cube.cpp:242
@@ -177,28 +179,23 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
         a2p = (float)((1.0 + (double)a2m1) - (double)kc.om_a2 * 0.75 * eps);
     }
 
-    // Bounding cone of the block's active canonical directions.
-    float sumx = active ? n.x : 0.f, sumy = active ? n.y : 0.f, sumz = active ? n.z : 0.f;
+    // Bounding cone of the wave's active canonical directions.
+    float axx = active ? n.x : 0.f, axy = active ? n.y : 0.f, axz = active ? n.z : 0.f;
     for (int off = 32; off > 0; off >>= 1) {
-        sumx += __shfl_xor(sumx, off); sumy += __shfl_xor(sumy, off); sumz += __shfl_xor(sumz, off);
+        axx += __shfl_xor(axx, off); axy += __shfl_xor(axy, off); axz += __shfl_xor(axz, off);
     }
-    if (lane == 0) { s_red[0][wave] = sumx; s_red[1][wave] = sumy; s_red[2][wave] = sumz; }
-    __syncthreads();
-    float axx = 0.f, axy = 0.f, axz = 0.f;
-    for (int w = 0; w < GO_THREADS / 64; w++) { axx += s_red[0][w]; axy += s_red[1][w]; axz += s_red[2][w]; }
     {
         float inv = rsqrtf(axx * axx + axy * axy + axz * axz);
         axx *= inv; axy *= inv; axz *= inv;
     }
     float cmin_dot = active ? (axx * n.x + axy * n.y + axz * n.z) : 1.0f;
     for (int off = 32; off > 0; off >>= 1) cmin_dot = fminf(cmin_dot, __shfl_xor(cmin_dot, off));
-    if (lane == 0) s_red[3][wave] = cmin_dot;
-    __syncthreads();
-    for (int w = 0; w < GO_THREADS / 64; w++) cmin_dot = fminf(cmin_dot, s_red[3][w]);
-    float block_thr;
+    // A patch can pass some lane's test only within theta_acc of that lane's direction,
+    // hence within theta_acc + cone radius of the axis (+ slack for rounding here).
+    float wave_thr;
     {
         float ang = theta_acc + acosf(fminf(fmaxf(cmin_dot, -1.0f), 1.0f)) + 4e-3f;
-        block_thr = ang >= 3.14159f ? -2.0f : cosf(ang);
+        wave_thr = ang >= 3.14159f ? -2.0f : cosf(ang);
     }
 
     float acc[8][4];
@@ -207,18 +204,19 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
     for (int m = 0; m < 8; m++)
 #pragma unroll
         for (int k = 0; k < 4; k++) { acc[m][k] = 0.0f; dacc[m][k] = 0.0; }
-    uint32_t n_tested = 0, n_accepted = 0;
+    uint32_t n_accepted = 0;
     unsigned long long tot_tested = 0, tot_accepted = 0;
 
     // Slices interleave the patch octets (slice s owns q = s, s + S, s + 2S, ...), so
     // every slice sees every region of the sphere and the workgroups of one output
     // tile carry equal shares of its cone.
     const uint32_t n_slices = gridDim.y;
-    const uint32_t my_count = (n_po + n_slices - 1 - blockIdx.y) / n_slices;   // patch octets of this slice
+    const uint32_t my_count = (n_po + n_slices - 1 - blockIdx.y) / n_slices;
 
-    for (uint32_t base = 0; base < my_count; base += GO_THREADS) {
-        // ---- candidates of this chunk: (patch octet, sign patterns), in patch order --
-        const uint32_t qi = base + tid;
+    for (uint32_t base = 0; base < my_count; base += 64) {
+        // ---- candidates among the next 64 patch octets of the slice: sign patterns whose
+        //      mirrored patch centre lies inside the wave's cone
+        const uint32_t qi = base + lane;
         const uint32_t q = qi * n_slices + blockIdx.y;
         uint32_t cmask = 0;
         if (qi < my_count) {
@@ -227,35 +225,15 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
 #pragma unroll
             for (int tau = 0; tau < 8; tau++) {
                 float dsum = ((tau & 1) ? -a : a) + ((tau & 2) ? -b : b) + ((tau & 4) ? -c : c);
-                if (dsum >= block_thr) cmask |= 1u << tau;
+                if (dsum >= wave_thr) cmask |= 1u << tau;
             }
         }
-        const bool cand = cmask != 0u;
-        const unsigned long long bal = __ballot(cand);
-        if (lane == 0) s_wcnt[wave] = __popcll(bal);
-        __syncthreads();
-        uint32_t offs = 0, n_cand = 0;
-        for (uint32_t w = 0; w < GO_THREADS / 64; w++) {
-            const uint32_t cw = s_wcnt[w];
-            if (w < wave) offs += cw;
-            n_cand += cw;
-        }
-        if (cand) {
-            const uint32_t pos = offs + __popcll(bal & ((1ull << lane) - 1ull));
-            s_list[pos] = q;
-            s_lmask[pos] = cmask;
-        }
-        __syncthreads();
-
-        for (uint32_t ci = 0; ci < n_cand; ci++) {
-            const uint32_t po = s_list[ci];
-            const uint32_t pmask = s_lmask[ci];
-            // stage the patch octet's records
-            {
-                const size_t gbase = (size_t)po * ps2 * GO_REC;
-                const uint32_t total = ps2 * GO_REC;
-                for (uint32_t idx = tid; idx < total; idx += GO_THREADS) s_rec[idx] = rec[gbase + idx];
-            }
+        unsigned long long bal = __ballot(cmask != 0u);
+        while (bal) {                                  // ascending patch order
+            const int src = __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            const uint32_t po = __builtin_amdgcn_readlane(q, src);
+            const uint32_t pmask = __builtin_amdgcn_readlane(cmask, src);
             // exact per-lane patch tests (cube.cpp:256-258), one per candidate pattern
             const float4 c4 = pn[po];
             float thr[8];
@@ -270,66 +248,105 @@ __global__ __launch_bounds__(GO_THREADS, 2) void ggx_oct_pairs(
                 thr[tau] = pass ? cmin : 2.0f;
                 lane_pass |= pass ? (1u << tau) : 0u;
             }
-            if (COUNT) n_tested += __popc(lane_pass) * ps2 * 8u;
-            if (COUNT && lane == 0) {
-                // diagnostic: lane slots the wave spends (64 lanes per executed pattern)
-                uint32_t wm = 0;
-                for (int tau = 0; tau < 8; tau++) if (__any((lane_pass >> tau) & 1u)) wm++;
-                atomicAdd(&counts[3], (unsigned long long)wm * ps2 * 8ull * 64ull);
-            }
-            // patterns that pass for any lane of this wave
+            if (COUNT) tot_tested += (unsigned long long)__popc(lane_pass) * ps2 * 8ull;
             uint32_t wmask = 0;
 #pragma unroll
             for (int tau = 0; tau < 8; tau++)
                 if (__any((lane_pass >> tau) & 1u)) wmask |= 1u << tau;
-            __syncthreads();
-            if (wmask != 0u) {
-                for (uint32_t e0 = 0; e0 < ps2; e0 += GO_FLUSH) {
-                    const uint32_t e1 = min(ps2, e0 + GO_FLUSH);
-                    if (wmask == 1u) {
-                        for (uint32_t e = e0; e < e1; e++) {
-                            float r[28];
+            if (wmask == 0u) continue;
+
+            const float4* __restrict__ rp = rec + (size_t)po * ps2 * GO_REC;   // wave-uniform
+            // FP32 chunk: about 512 terms per accumulator (every record adds one term per
+            // passing pattern).  wmask depends only on which octets share the wave, and
+            // waves are fixed 64-octet groups of the level, so this choice is the same for
+            // every way of splitting a bake.
+            const uint32_t npat = __popc(wmask);
+            const uint32_t flush = npat <= 2 ? 256u : (npat <= 4 ? 128u : (uint32_t)GO_FLUSH);
+            for (uint32_t e0 = 0; e0 < ps2; e0 += flush) {
+                const uint32_t e1 = min(ps2, e0 + flush);
+                // Two scalar register sets: the next record is fetched while the current
+                // one is evaluated (ping-pong, so nothing is copied).
+                float4 ra[GO_REC], rb[GO_REC];
+                auto load = [&](float4 (&dst)[GO_REC], uint32_t e) {
+#ifdef GO_FAKE_LOADS   // timing experiment only: every record read is the patch's first record
+                    const float4* __restrict__ p = rp + (size_t)(e & 0u) * GO_REC;
+#else
+                    const float4* __restrict__ p = rp + (size_t)min(e, ps2 - 1) * GO_REC;
+#endif
 #pragma unroll
-                            for (int qq = 0; qq < GO_REC; qq++) {
-                                const float4 t4 = s_rec[e * GO_REC + qq];
-                                r[4 * qq] = t4.x; r[4 * qq + 1] = t4.y; r[4 * qq + 2] = t4.z; r[4 * qq + 3] = t4.w;
-                            }
-                            float c = n.x * r[0];
-                            c = fmaf(n.y, r[1], c);
-                            c = fmaf(n.z, r[2], c);
-                            go_body<0, COUNT>(c, r, thr[0], a2p, kc, acc, n_accepted);
-                        }
-                    } else {
-                        for (uint32_t e = e0; e < e1; e++) {
-                            float r[28];
+                    for (int qq = 0; qq < GO_REC; qq++) dst[qq] = p[qq];
+                };
+                auto unpack = [&](const float4 (&src)[GO_REC], float (&r)[28]) {
 #pragma unroll
-                            for (int qq = 0; qq < GO_REC; qq++) {
-                                const float4 t4 = s_rec[e * GO_REC + qq];
-                                r[4 * qq] = t4.x; r[4 * qq + 1] = t4.y; r[4 * qq + 2] = t4.z; r[4 * qq + 3] = t4.w;
-                            }
-                            const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
-                            const float s1 = a + b, s2 = a - b;
-                            if (wmask & 1u)   go_body<0, COUNT>(s1 + cc, r, thr[0], a2p, kc, acc, n_accepted);
-                            if (wmask & 2u)   go_body<1, COUNT>(cc - s2, r, thr[1], a2p, kc, acc, n_accepted);
-                            if (wmask & 4u)   go_body<2, COUNT>(s2 + cc, r, thr[2], a2p, kc, acc, n_accepted);
-                            if (wmask & 8u)   go_body<3, COUNT>(cc - s1, r, thr[3], a2p, kc, acc, n_accepted);
-                            if (wmask & 16u)  go_body<4, COUNT>(s1 - cc, r, thr[4], a2p, kc, acc, n_accepted);
-                            if (wmask & 32u)  go_body<5, COUNT>(-s2 - cc, r, thr[5], a2p, kc, acc, n_accepted);
-                            if (wmask & 64u)  go_body<6, COUNT>(s2 - cc, r, thr[6], a2p, kc, acc, n_accepted);
-                            if (wmask & 128u) go_body<7, COUNT>(-s1 - cc, r, thr[7], a2p, kc, acc, n_accepted);
-                        }
+                    for (int qq = 0; qq < GO_REC; qq++) {
+                        r[4 * qq] = src[qq].x; r[4 * qq + 1] = src[qq].y; r[4 * qq + 2] = src[qq].z; r[4 * qq + 3] = src[qq].w;
                     }
-#pragma unroll
-                    for (int m = 0; m < 8; m++)
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { dacc[m][k] += (double)acc[m][k]; acc[m][k] = 0.0f; }
+                };
+                // Scalar loads return out of order, so the only wait is "all of them":
+                // the first use of a record must come BEFORE the next record's loads are
+                // issued, or that wait would cover the prefetch too.  touch() is that first
+                // use; the scheduling barriers keep the order.
+                auto touch = [&](const float4 (&src)[GO_REC]) {
+                    float c = n.x * src[0].x;
+                    c = fmaf(n.y, src[0].y, c);
+                    c = fmaf(n.z, src[0].z, c);
+                    return c;
+                };
+                auto eval_one = [&](const float4 (&src)[GO_REC], float c) {
+                    float r[28];
+                    unpack(src, r);
+                    go_body<0, COUNT>(c, r, thr[0], a2p, kc, acc, n_accepted);
+                };
+                auto eval_all = [&](const float4 (&src)[GO_REC]) {
+                    float r[28];
+                    unpack(src, r);
+                    const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
+                    const float s1 = a + b, s2 = a - b;
+                    if (wmask & 1u)   go_body<0, COUNT>(s1 + cc, r, thr[0], a2p, kc, acc, n_accepted);
+                    if (wmask & 2u)   go_body<1, COUNT>(cc - s2, r, thr[1], a2p, kc, acc, n_accepted);
+                    if (wmask & 4u)   go_body<2, COUNT>(s2 + cc, r, thr[2], a2p, kc, acc, n_accepted);
+                    if (wmask & 8u)   go_body<3, COUNT>(cc - s1, r, thr[3], a2p, kc, acc, n_accepted);
+                    if (wmask & 16u)  go_body<4, COUNT>(s1 - cc, r, thr[4], a2p, kc, acc, n_accepted);
+                    if (wmask & 32u)  go_body<5, COUNT>(-s2 - cc, r, thr[5], a2p, kc, acc, n_accepted);
+                    if (wmask & 64u)  go_body<6, COUNT>(s2 - cc, r, thr[6], a2p, kc, acc, n_accepted);
+                    if (wmask & 128u) go_body<7, COUNT>(-s1 - cc, r, thr[7], a2p, kc, acc, n_accepted);
+                };
+                load(ra, e0);
+                if (wmask == 1u) {
+                    for (uint32_t e = e0; e < e1; e += 2) {
+                        const float ca = touch(ra);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load(rb, e + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        eval_one(ra, ca);
+                        const float cb = touch(rb);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load(ra, e + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (e + 1 < e1) eval_one(rb, cb);
+                    }
+                } else {
+                    for (uint32_t e = e0; e < e1; e += 2) {
+                        float keep = touch(ra);
+                        asm volatile("" :: "v"(keep));
+                        __builtin_amdgcn_sched_barrier(0);
+                        load(rb, e + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        eval_all(ra);
+                        keep = touch(rb);
+                        asm volatile("" :: "v"(keep));
+                        __builtin_amdgcn_sched_barrier(0);
+                        load(ra, e + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (e + 1 < e1) eval_all(rb);
+                    }
                 }
+#pragma unroll
+                for (int m = 0; m < 8; m++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { dacc[m][k] += (double)acc[m][k]; acc[m][k] = 0.0f; }
             }
-            __syncthreads();
-        }
-        if (COUNT) {
-            tot_tested += n_tested; tot_accepted += (unsigned long long)n_accepted * 8ull;
-            n_tested = 0; n_accepted = 0;
+            if (COUNT) { tot_accepted += (unsigned long long)n_accepted * 8ull; n_accepted = 0; }
         }
     }
 
