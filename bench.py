@@ -315,6 +315,14 @@ def main():
                 "traffic": None,
             },
         }
+        try:   # measured HBM traffic of the same launch, from the committed rocprofv3 PMC passes
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tr = json.load(f).get(wl.name)
+            if tr and world == 1:
+                line["roofline"]["traffic"] = tr["bytes"]
+                line["roofline"]["traffic_source"] = tr["source"]
+        except OSError:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -366,28 +366,27 @@ __global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
     }
 }
 
+// One thread per (output octet, member): coalesced over the octet index.
 __global__ __launch_bounds__(256) void ggx_oct_final(const double* __restrict__ partial, uint32_t n_slices,
                                                       uint32_t out_w, uint32_t tw, uint32_t first_block,
                                                       uint32_t block_stride, uint32_t n_oct, uint32_t oct_count,
                                                       uint32_t out_begin, uint32_t out_count, float4* __restrict__ out) {
     const uint32_t lo = blockIdx.x * GO_THREADS + threadIdx.x;
     const uint32_t gidx = (blockIdx.x * block_stride + first_block) * GO_THREADS + threadIdx.x;
+    const uint32_t m = blockIdx.y;
     if (gidx >= n_oct) return;
     uint32_t axis, oj, oi;
     go_decode(gidx, out_w / 2, tw, axis, oj, oi);
-    for (uint32_t m = 0; m < 8; m++) {
-        Texel t = octet_member(axis, oj, oi, m, out_w, out_w);
-        uint32_t o = (t.face * out_w + t.y) * out_w + t.x;
-        if (o - out_begin >= out_count) continue;
-        double v[4];
-        for (uint32_t k = 0; k < 4; k++) {
-            double sum = 0.0;
-            for (uint32_t sl = 0; sl < n_slices; sl++) sum += partial[((size_t)sl * 32 + (m * 4 + k)) * oct_count + lo];
-            v[k] = sum;
-        }
-        double inv = 1.0 / v[0];   // cube.cpp:305 via linear.hpp:93-95
-        out[o] = make_float4((float)(inv * v[1]), (float)(inv * v[2]), (float)(inv * v[3]), 0.0f);
+    Texel t = octet_member(axis, oj, oi, m, out_w, out_w);
+    const uint32_t o = (t.face * out_w + t.y) * out_w + t.x;
+    if (o - out_begin >= out_count) return;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (uint32_t sl = 0; sl < n_slices; sl++) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) v[k] += partial[((size_t)sl * 32 + (m * 4 + k)) * oct_count + lo];
     }
+    double inv = 1.0 / v[0];   // cube.cpp:305 via linear.hpp:93-95
+    out[o] = make_float4((float)(inv * v[1]), (float)(inv * v[2]), (float)(inv * v[3]), 0.0f);
 }
 
 // ---- launch plan -----------------------------------------------------------
@@ -448,7 +447,7 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
             pl.po_per_slice, ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, d_partial, d_counts);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    ggx_oct_final<<<pl.out_blocks, GO_THREADS, 0, stream>>>(d_partial, pl.n_slices, out_w, pl.tw, first_block,
+    ggx_oct_final<<<dim3(pl.out_blocks, 8), GO_THREADS, 0, stream>>>(d_partial, pl.n_slices, out_w, pl.tw, first_block,
                                                             block_stride, n_oct, oct_count, out_begin, out_count,
                                                             (float4*)d_out);
     return hipGetLastError();

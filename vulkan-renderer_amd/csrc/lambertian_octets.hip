@@ -178,29 +178,28 @@ __global__ __launch_bounds__(OCT_THREADS, 2) void lambertian_oct_pairs(
     }
 }
 
+// One thread per (output octet, member): coalesced over the octet index.
 __global__ __launch_bounds__(256) void lambertian_oct_final(const double* __restrict__ partial, uint32_t n_slices,
                                                              uint32_t out_size, uint32_t oct_begin, uint32_t oct_count,
                                                              uint32_t out_begin, uint32_t out_count, double scale,
                                                              float4* __restrict__ out) {
-    uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.y;
     if (lo >= oct_count) return;
     const uint32_t hw = out_size / 2;
     const uint32_t oo = oct_begin + lo;
     const uint32_t axis = oo / (hw * hw);
     const uint32_t rem = oo - axis * (hw * hw);
     const uint32_t oj = rem / hw, oi = rem - oj * hw;
-    for (uint32_t s = 0; s < 8; s++) {
-        Texel t = octet_member(axis, oj, oi, s, out_size, out_size);
-        uint32_t o = (t.face * out_size + t.y) * out_size + t.x;
-        if (o - out_begin >= out_count) continue;
-        double v[3];
-        for (uint32_t k = 0; k < 3; k++) {
-            double sum = 0.0;
-            for (uint32_t sl = 0; sl < n_slices; sl++) sum += partial[((size_t)sl * 24 + (s * 3 + k)) * oct_count + lo];
-            v[k] = sum * scale;
-        }
-        out[o] = make_float4((float)v[0], (float)v[1], (float)v[2], 0.0f);
+    Texel t = octet_member(axis, oj, oi, s, out_size, out_size);
+    const uint32_t o = (t.face * out_size + t.y) * out_size + t.x;
+    if (o - out_begin >= out_count) return;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (uint32_t sl = 0; sl < n_slices; sl++) {
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) v[k] += partial[((size_t)sl * 24 + (s * 3 + k)) * oct_count + lo];
     }
+    out[o] = make_float4((float)(v[0] * scale), (float)(v[1] * scale), (float)(v[2] * scale), 0.0f);
 }
 
 // ---- launch plan -----------------------------------------------------------
@@ -233,7 +232,7 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
                                                            oct_begin, oct_count, out_begin, out_count, d_partial);
     if (ev1) (void)hipEventRecord(ev1, stream);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);
-    lambertian_oct_final<<<(oct_count + 255) / 256, 256, 0, stream>>>(d_partial, pl.n_slices, out_size, oct_begin,
+    lambertian_oct_final<<<dim3((oct_count + 255) / 256, 8), 256, 0, stream>>>(d_partial, pl.n_slices, out_size, oct_begin,
                                                                       oct_count, out_begin, out_count, scale,
                                                                       (float4*)d_out);
     return hipGetLastError();
