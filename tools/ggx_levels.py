@@ -2,7 +2,6 @@
 
     python tools/ggx_levels.py [in_w] [min_size] [downscale]
 """
-import ctypes
 import os
 import sys
 
@@ -30,9 +29,6 @@ def main():
             ibl.set_counting(True)
             ibl.ggx_level(env, ow, m, mips)
             c = ibl.last_counts()
-            slots = ctypes.c_uint64()
-            ibl.lib.ibl_debug_counter.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
-            ibl.lib.ibl_debug_counter(3, ctypes.byref(slots))
             ibl.set_counting(False)
             best = 1e9
             for _ in range(2):
@@ -43,8 +39,7 @@ def main():
             flop = 30.0 * c["accepted"] + 8.0 * (c["tested"] - c["accepted"])
             print("%-8s level %d out %4d r=%.3f cutoff=%.3f tested %.3e accepted %.3e  %.3f ms  %.1f Gtested/s  %.1f TFLOP/s(alg)"
                   % (mode, m, ow, p["roughness"], p["cutoff"], c["tested"], c["accepted"], best,
-                     c["tested"] / best / 1e6, flop / best / 1e9)
-                  + ("  lane-util %.3f" % (c["tested"] / slots.value) if slots.value else ""))
+                     c["tested"] / best / 1e6, flop / best / 1e9))
         print("%-8s chain kernel total %.3f ms" % (mode, total))
 
 

@@ -183,17 +183,6 @@ int ibl_last_kernel_ms(float* ms) {
     return IBL_OK;
 }
 
-// Diagnostic (not part of the ABI): raw device counter `idx` of the last counted call.
-int ibl_debug_counter(int idx, uint64_t* value) {
-    if (int rc = check_ready()) return rc;
-    if (!g.counts.ptr || idx < 0 || idx > 3 || !value) return fail(IBL_EINVAL, "no counters");
-    unsigned long long h[4];
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h, g.counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
-    *value = h[idx];
-    return IBL_OK;
-}
-
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
     if (int rc = check_ready()) return rc;
     if (g.counts_pending) {

@@ -24,7 +24,7 @@
 //   ggx_prep / ggx_prep_patches   per level: unit directions + |w|^-3 and
 //       radiance*|w|^-3 per input texel, stored PATCH-MAJOR so the texels of one
 //       patch are one contiguous run; unit centre direction per patch.
-//   ggx_pairs   grid = (output tiles) x (patch slices).  A workgroup owns a tile
+//   ggx_pairs   grid = (output tiles) x (interleaved patch slices).  A workgroup owns a tile
 //       of 16PX x 16PY output texels (PX*PY per thread, directions in registers).
 //       It walks its slice of patches 256 at a time: a conservative bounding-cone
 //       test compacts the candidates into an LDS list in patch order, then each
@@ -190,14 +190,18 @@ __global__ __launch_bounds__(GGX_THREADS, 2) void ggx_pairs(
     }
     unsigned long long tot_tested = 0, tot_accepted = 0;
 
-    const uint32_t p0 = blockIdx.y * patches_per_slice;
-    const uint32_t p1 = min(n_patches, p0 + patches_per_slice);
+    // Slices interleave the patches (slice s owns q = s, s + S, s + 2S, ...) so that the
+    // workgroups of one output tile carry equal shares of its cone.
+    const uint32_t n_slices = gridDim.y;
+    const uint32_t my_count = (n_patches + n_slices - 1 - blockIdx.y) / n_slices;
+    (void)patches_per_slice;
 
-    for (uint32_t base = p0; base < p1; base += GGX_THREADS) {
+    for (uint32_t base = 0; base < my_count; base += GGX_THREADS) {
         // ---- candidate list of this chunk, in patch order --------------------
-        uint32_t q = base + tid;
+        const uint32_t qi = base + tid;
+        uint32_t q = qi * n_slices + blockIdx.y;
         bool cand = false;
-        if (q < p1) {
+        if (qi < my_count) {
             float4 c4 = pn[q];
             cand = (c4.x * axx + c4.y * axy + c4.z * axz) >= block_thr;
         }
@@ -329,12 +333,12 @@ GgxPlan ggx_plan(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h, u
     pl.tiles_x = (out_w + 16 * pl.px - 1) / (16 * pl.px);
     pl.tiles_y = (out_h + 16 * pl.py - 1) / (16 * pl.py);
     uint32_t tiles = 6 * pl.tiles_x * pl.tiles_y;
-    uint32_t want = (1536 + tiles - 1) / tiles;                 // slices wanted for ~1536 workgroups
-    uint32_t max_slices = (pl.n_patches + 15) / 16;             // >= 16 patches per slice
+    uint32_t want = (3072 + tiles - 1) / tiles;                 // slices wanted for ~3072 workgroups
+    uint32_t max_slices = (pl.n_patches + 3) / 4;               // >= 4 patches per slice
     if (max_slices == 0) max_slices = 1;
     uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
     pl.patches_per_slice = (pl.n_patches + slices - 1) / slices;
-    pl.n_slices = (pl.n_patches + pl.patches_per_slice - 1) / pl.patches_per_slice;
+    pl.n_slices = slices;
     pl.partial_bytes = (size_t)pl.n_slices * out_count * 4 * sizeof(double);
     const size_t n_in = (size_t)pl.n_patches * ps * ps;
     pl.prep_bytes_a = n_in * sizeof(float4);

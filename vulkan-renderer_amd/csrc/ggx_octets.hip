@@ -139,7 +139,7 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
 template <bool COUNT>
 __global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn,
-    uint32_t n_po, uint32_t po_per_slice, uint32_t ps2,
+    uint32_t n_po, uint32_t ps2,
     uint32_t out_w, uint32_t tw, uint32_t first_block, uint32_t block_stride, uint32_t n_oct, uint32_t oct_local,
     uint32_t out_begin, uint32_t out_count,
     float cutoff, float a2m1, float cmin, float theta_acc,
@@ -268,11 +268,7 @@ __global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
                 // one is evaluated (ping-pong, so nothing is copied).
                 float4 ra[GO_REC], rb[GO_REC];
                 auto load = [&](float4 (&dst)[GO_REC], uint32_t e) {
-#ifdef GO_FAKE_LOADS   // timing experiment only: every record read is the patch's first record
-                    const float4* __restrict__ p = rp + (size_t)(e & 0u) * GO_REC;
-#else
                     const float4* __restrict__ p = rp + (size_t)min(e, ps2 - 1) * GO_REC;
-#endif
 #pragma unroll
                     for (int qq = 0; qq < GO_REC; qq++) dst[qq] = p[qq];
                 };
@@ -440,11 +436,11 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (d_counts)
         ggx_oct_pairs<true><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
-            pl.po_per_slice, ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
+            ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, d_partial, d_counts);
     else
         ggx_oct_pairs<false><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
-            pl.po_per_slice, ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
+            ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, d_partial, d_counts);
     if (ev1) (void)hipEventRecord(ev1, stream);
     ggx_oct_final<<<dim3(pl.out_blocks, 8), GO_THREADS, 0, stream>>>(d_partial, pl.n_slices, out_w, pl.tw, first_block,
