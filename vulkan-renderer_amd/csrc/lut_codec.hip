@@ -1,11 +1,11 @@
 // Split-sum BRDF table, RGBE codec and box downscale for gfx950.
 //
 // brdf_lut_cells   generateGGXLUT's cell loop, src/utilities/cube.cpp:346-385.
-//     One 256-thread workgroup per (roughness, cos theta_v) cell; the
-//     samples_sqrt^2 strata are dealt round-robin to the threads, every thread
-//     keeps FP64 slope/bias sums, and the workgroup combines them with a
-//     fixed-shape wavefront butterfly + LDS tree, so a cell's value depends on
-//     (seed, cell, samples_sqrt) only.  The per-sample arithmetic keeps the
+//     One wavefront per (roughness, cos theta_v) cell (four cells per 256-thread
+//     workgroup); the samples_sqrt^2 strata are dealt round-robin to the 64
+//     lanes, every lane keeps FP64 slope/bias sums, and a fixed-shape wavefront
+//     butterfly combines them, so a cell's value depends on
+//     (seed, cell, samples_sqrt) only.  No LDS.  The per-sample arithmetic keeps the
 //     reference's mix of float and double (angles and trig in double, BRDF terms
 //     in float).  The reference seeds std::mt19937 from std::random_device; here
 //     the jitter is a counter-based hash of (seed, cell, sample) or the stratum
@@ -26,10 +26,12 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 
 __global__ __launch_bounds__(256) void brdf_lut_cells(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt,
                                                        uint64_t seed, int mode, uint32_t cell_begin,
-                                                       float2* __restrict__ out) {
+                                                       uint32_t cell_count, float2* __restrict__ out) {
 #pragma clang fp contract(off)
-    __shared__ double s_slope[4], s_bias[4];
-    const uint32_t cell = cell_begin + blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t local = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (local >= cell_count) return;            // whole wave leaves: no barrier below
+    const uint32_t cell = cell_begin + local;
     const uint32_t ri = cell / n_cos, ci = cell - ri * n_cos;
     const float roughness = (float)(((double)(float)ri + 0.5) / (double)n_rough);
     const float alpha = roughness * roughness;
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void brdf_lut_cells(uint32_t n_rough, uint32_t
     const uint32_t n_samples = samples_sqrt * samples_sqrt;
 
     double slope = 0.0, bias = 0.0;
-    for (uint32_t s = threadIdx.x; s < n_samples; s += blockDim.x) {
+    for (uint32_t s = lane; s < n_samples; s += 64) {
         const uint32_t sx = s / samples_sqrt, sy = s - sx * samples_sqrt;
         double j1, j2;
         if (mode == 1) {
@@ -81,15 +83,10 @@ __global__ __launch_bounds__(256) void brdf_lut_cells(uint32_t n_rough, uint32_t
         slope += __shfl_xor(slope, off);
         bias += __shfl_xor(bias, off);
     }
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_slope[wave] = slope; s_bias[wave] = bias; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = (s_slope[0] + s_slope[1]) + (s_slope[2] + s_slope[3]);
-        double b = (s_bias[0] + s_bias[1]) + (s_bias[2] + s_bias[3]);
-        s /= (double)n_samples;
-        b /= (double)n_samples;
-        out[cell] = make_float2((float)s, (float)b);
+    if (lane == 0) {
+        slope /= (double)n_samples;
+        bias /= (double)n_samples;
+        out[cell] = make_float2((float)slope, (float)bias);
     }
 }
 
@@ -98,8 +95,8 @@ hipError_t brdf_lut_launch(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sq
                            hipEvent_t ev0, hipEvent_t ev1) {
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (cell_count)
-        brdf_lut_cells<<<cell_count, 256, 0, stream>>>(n_rough, n_cos, samples_sqrt, seed, mode, cell_begin,
-                                                       (float2*)d_out);
+        brdf_lut_cells<<<(cell_count + 3) / 4, 256, 0, stream>>>(n_rough, n_cos, samples_sqrt, seed, mode, cell_begin,
+                                                                 cell_count, (float2*)d_out);
     if (ev1) (void)hipEventRecord(ev1, stream);
     return hipGetLastError();
 }
