@@ -107,6 +107,13 @@ int ibl_rgbe_encode_dev(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, void* 
 /* The box filter of main, cube.cpp:482-501: (w x 6h) strip -> (w/d x 6h/d). */
 int ibl_downscale_dev(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, void* stream);
 
+/* getNormalFrom followed by linear::normalize, src/utilities/cube.cpp:31-50 with
+ * include/linear.hpp:114-122: the unit direction of every texel of a w x h x 6 cube,
+ * as both integrals compute it (cube.cpp:97,197,242).  d_out receives w*h*6 float4
+ * (x, y, z, 0) in (face, y, x) order.  normalized == 0 stores the unnormalised
+ * getNormalFrom vector instead (cube.cpp:103,187). */
+int ibl_texel_directions_dev(uint32_t w, uint32_t h, int normalized, float* d_out, void* stream);
+
 /* ---- host-buffer entry points -------------------------------------------- */
 
 int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* out);

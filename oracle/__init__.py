@@ -36,6 +36,8 @@ def lib():
         L = ctypes.CDLL(_LIB_PATH)
         L.orc_normal_from.argtypes = [_u32, _u32, _u32, _u32, _u32, _f32p]
         L.orc_normal_from.restype = None
+        L.orc_texel_directions.argtypes = [_u32, _u32, ctypes.c_int, _f32p]
+        L.orc_texel_directions.restype = None
         L.orc_lambertian.argtypes = [_f32p, _u32, _u32, _u32, _u32, _u32, _f32p, ctypes.c_int]
         L.orc_lambertian.restype = ctypes.c_int
         L.orc_ggx_mip_levels.argtypes = [_u32, _u32, _u32]
@@ -65,6 +67,14 @@ def lib():
 def normal_from(face, x, y, w, h):
     out = np.zeros(3, np.float32)
     lib().orc_normal_from(face, x, y, w, h, out)
+    return out
+
+
+def texel_directions(w, h=None, normalized=True):
+    """(6, h, w, 4) float32 direction of every texel (w component 0)."""
+    h = w if h is None else h
+    out = np.zeros((6, h, w, 4), np.float32)
+    lib().orc_texel_directions(w, h, int(bool(normalized)), out.reshape(-1))
     return out
 
 

@@ -82,6 +82,20 @@ void orc_normal_from(uint32_t face, uint32_t x, uint32_t y, uint32_t w, uint32_t
     out[0] = n.x; out[1] = n.y; out[2] = n.z;
 }
 
+/* The direction table both integrals start from: getNormalFrom for every texel in
+ * (face, y, x) order, normalised as at cube.cpp:97,197,242 or raw as at
+ * cube.cpp:103,187.  out holds w*h*6 float4 (x, y, z, 0). */
+void orc_texel_directions(uint32_t w, uint32_t h, int normalized, float* out) {
+    for (uint32_t f = 0; f < 6; f++)
+        for (uint32_t y = 0; y < h; y++)
+            for (uint32_t x = 0; x < w; x++) {
+                v3f n = normal_from(f, x, y, w, h);
+                if (normalized) n = normalize3(n);
+                float* o = out + 4 * (((size_t)f * h + y) * w + x);
+                o[0] = n.x; o[1] = n.y; o[2] = n.z; o[3] = 0.0f;
+            }
+}
+
 /* ------------------------------------------------------------- Lambertian */
 
 /* integrateLambertian's parallel loop, src/utilities/cube.cpp:95-129, for the

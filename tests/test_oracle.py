@@ -20,6 +20,25 @@ def test_normal_from_matches_face_table(orc):
         np.testing.assert_array_equal(orc.normal_from(face, 1, 2, 4, 4), np.asarray(w, np.float32))
 
 
+def test_texel_direction_table(orc):
+    # the table agrees with single-texel getNormalFrom calls, is correctly rounded
+    # (numpy float32 sqrt and division are IEEE), and mirrors exactly for even sizes
+    w, h = 12, 6
+    raw = orc.texel_directions(w, h, normalized=False)
+    unit = orc.texel_directions(w, h, normalized=True)
+    f32 = np.float32
+    for f, y, x in [(0, 0, 0), (1, 5, 11), (2, 3, 7), (3, 2, 2), (4, 0, 9), (5, 5, 0)]:
+        d = orc.normal_from(f, x, y, w, h)
+        np.testing.assert_array_equal(raw[f, y, x, :3], d)
+        r = f32(d[0] * d[0]); r = f32(r + f32(d[1] * d[1])); r = f32(r + f32(d[2] * d[2]))
+        inv = f32(f32(1) / np.sqrt(r))
+        np.testing.assert_array_equal(unit[f, y, x, :3], (d * inv).astype(f32))
+    assert (raw[..., 3] == 0).all() and (unit[..., 3] == 0).all()
+    # face 0 (+X): (1, -t, -s); mirrored column has the opposite z
+    np.testing.assert_array_equal(unit[0, :, ::-1, 2], -unit[0, :, :, 2])
+    np.testing.assert_array_equal(unit[0, ::-1, :, 1], -unit[0, :, :, 1])
+
+
 def test_constant_environment_known_answers(orc):
     # cube.cpp:112-126: the Lambertian weights sum to ~1 (quadrature error only);
     # cube.cpp:303-305: GGX divides by the summed weights, so a constant stays put.

@@ -19,12 +19,11 @@ REL_TOL = 1e-3          # north-star radiance tolerance
 BYTE_FRACTION = 0.999   # north-star RGBE criterion
 LUT_TOL = 1e-4          # north-star table tolerance
 # The reference evaluates the GGX denominator NoH^2*(a2-1)+1 in float, where it
-# cancels to ~a2: its own rounding noise is ~1e-7/a2 per (output, input) pair
-# (6e-5 at roughness 0.2).  That noise averages out over the lobe but cannot be
-# reproduced without repeating the reference's instruction sequence, so single
-# HDR-dominated texels differ by up to a few 1e-5; the north-star bars are 1e-3
-# and 99.9 %.
-GGX_TIGHT = 1e-4
+# cancels to ~a2: its rounding is ~1e-7/a2 per (output, input) pair.  The kernels
+# repeat the reference's instruction sequence inside the lobe core of narrow lobes
+# and use a cancellation-free form elsewhere; what is left is ~1e-7 on average and
+# ~1e-5 on single texels that a few very bright inputs dominate.
+GGX_TIGHT = 3e-5
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -71,7 +70,19 @@ def _check_cube(orc, got, want, sel=None, tight=5e-6, label=""):
     return err.max(), frac
 
 
-# ---- codec and box filter: bit-exact ------------------------------------------------
+# ---- texel directions, codec and box filter: bit-exact ------------------------------
+
+@pytest.mark.parametrize("w,h", [(16, 16), (17, 17), (30, 30), (24, 12), (64, 64), (256, 256), (1024, 1024)])
+@pytest.mark.parametrize("normalized", [True, False])
+def test_texel_directions_bit_exact(ibl, orc, w, h, normalized):
+    """getNormalFrom + normalize (cube.cpp:31-50, linear.hpp:114-122): every yes/no
+    decision of the GGX cull and every cosine starts from this table, so it has to
+    match the CPU to the last bit (correctly rounded sqrt and division included)."""
+    got = ibl.texel_directions(w, h, normalized).cpu().numpy()
+    want = orc.texel_directions(w, h, normalized)
+    assert got.shape == want.shape
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
 
 def test_rgbe_decode_bit_exact(ibl, orc):
     rng = np.random.default_rng(0)
@@ -121,7 +132,7 @@ def test_downscale_rejects_bad_factor(ibl, orc):
 
 # ---- Lambertian --------------------------------------------------------------------------
 
-@pytest.mark.parametrize("w,out", [(16, 8), (64, 32), (32, 5), (128, 16)])
+@pytest.mark.parametrize("w,out", [(16, 8), (64, 32), (32, 5), (128, 16), (24, 6), (30, 10), (17, 3)])
 def test_lambertian_parity(ibl, orc, w, out, kernel_mode):
     env, env_d = _env(ibl, orc, w)
     got = ibl.lambertian(env_d, out).cpu().numpy()
@@ -146,7 +157,7 @@ def test_lambertian_special_environments(ibl, orc, kind, kernel_mode):
         assert zero.any() and (got[..., :3][zero] == 0).all()
     # one term only: at grazing incidence its dot product cancels, so the per-texel
     # error is a few float ulps of the operands, not of the result
-    _check_cube(orc, got, want, tight=5e-5 if kind == "single" else 5e-6)
+    _check_cube(orc, got, want, tight=2e-5 if kind == "single" else 5e-6)
 
 
 def test_lambertian_large_input_subset(ibl, orc, kernel_mode):
@@ -197,7 +208,7 @@ def test_lambertian_full_size_properties(ibl, orc, kernel_mode):
 
 # ---- GGX ---------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("w,min_size", [(16, 8), (64, 16), (64, 4), (128, 16)])
+@pytest.mark.parametrize("w,min_size", [(16, 8), (64, 16), (64, 4), (128, 16), (48, 12), (96, 20)])
 def test_ggx_chain_parity(ibl, orc, w, min_size, kernel_mode):
     env, env_d = _env(ibl, orc, w)
     mips = orc.ggx_mip_levels(w, w, min_size)
@@ -249,6 +260,22 @@ def test_ggx_512_subset_16x16_patches(ibl, orc, kernel_mode):
         got = ibl.ggx_level(env_d, ow, m, mips, out_begin=begin, out_count=count).cpu().numpy()
         want = orc.ggx_level(env, ow, ow, m, mips, out_begin=begin, out_count=count)
         _check_cube(orc, got, want, sel=slice(begin, begin + count), tight=GGX_TIGHT, label="ggx 512 level %d" % m)
+
+
+def test_ggx_2048_subset(ibl, orc):
+    """BASELINE config 5's input (2048x2048/face, 7 levels): 96 output texels of four
+    levels against the oracle (the 25M-texel environment makes more too slow on CPU)."""
+    env, env_d = _env(ibl, orc, 2048, seed=9)
+    mips = orc.ggx_mip_levels(2048, 2048, 16)
+    assert mips == 7
+    for m in (1, 2, 4, 7):
+        ow = 2048 >> m
+        n_out = 6 * ow * ow
+        count = 96
+        begin = (n_out // 3) + 5
+        got = ibl.ggx_level(env_d, ow, m, mips, out_begin=begin, out_count=count).cpu().numpy()
+        want = orc.ggx_level(env, ow, ow, m, mips, out_begin=begin, out_count=count)
+        _check_cube(orc, got, want, sel=slice(begin, begin + count), tight=GGX_TIGHT, label="ggx 2048 level %d" % m)
 
 
 def test_ggx_full_size_properties(ibl, orc, kernel_mode):

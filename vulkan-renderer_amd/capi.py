@@ -41,6 +41,7 @@ _SIGNATURES = {
     "ibl_rgbe_decode_dev": ([_vp, _vp, _u32, _vp], _int),
     "ibl_rgbe_encode_dev": ([_vp, _vp, _u32, _vp], _int),
     "ibl_downscale_dev": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_texel_directions_dev": ([_u32, _u32, _int, _vp, _vp], _int),
     "ibl_lambertian": ([_vp, _u32, _u32, _u32, _vp], _int),
     "ibl_ggx_level": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp], _int),
     "ibl_brdf_lut": ([_u32, _u32, _u32, _u64, _int, _vp], _int),
@@ -216,6 +217,13 @@ class Ibl:
         out = self.torch.empty((6, max(h // max(d, 1), 1), max(w // max(d, 1), 1), 4), dtype=self.torch.float32,
                                device=self.device)
         self._check(self.lib.ibl_downscale_dev(_ptr(env), w, h, d, _ptr(out), self._stream(stream)))
+        return out
+
+    def texel_directions(self, w, h=None, normalized=True, stream=None):
+        """(6, h, w, 4) float32: the direction of every texel (getNormalFrom, normalised or raw)."""
+        h = w if h is None else h
+        out = self.torch.empty((6, h, w, 4), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.ibl_texel_directions_dev(w, h, int(bool(normalized)), _ptr(out), self._stream(stream)))
         return out
 
     # -- measurement --------------------------------------------------------------------

@@ -432,6 +432,15 @@ int ibl_downscale_dev(const float* d_env, uint32_t w, uint32_t h, uint32_t d, fl
     return IBL_OK;
 }
 
+int ibl_texel_directions_dev(uint32_t w, uint32_t h, int normalized, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_out) return fail(IBL_EINVAL, "texel_directions: null pointer");
+    if (w == 0 || h == 0 || (uint64_t)w * h * 6 > 0xffffffffull)
+        return fail(IBL_EINVAL, "texel_directions: bad cube size %u x %u", w, h);
+    HIP_TRY(ibl::texel_directions_launch(w, h, normalized, d_out, pick(stream)));
+    return IBL_OK;
+}
+
 // ---- host-buffer entry points ---------------------------------------------------
 
 namespace {

@@ -34,6 +34,7 @@
 #include "ibl_device.h"
 #include "ibl_kernels.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace ibl {
 
@@ -102,16 +103,29 @@ __global__ __launch_bounds__(256) void ggx_oct_prep_patches(uint32_t pw, uint32_
 
 struct GoConst {
     float cutoff, om_a2, cmin;
+    float core_thr;   // below this denominator the reference's own rounding is reproduced (0: never)
 };
 
 // One sign pattern TAU of one record: weight from the cosine, added to all 8 members.
 template <int TAU, bool COUNT>
 __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr, float a2p, const GoConst& k,
-                                        float (&acc)[8][4], uint32_t& n_acc) {
+                                        const F3& n, float (&acc)[8][4], uint32_t& n_acc) {
     float u = fmaf(-0.5f, c, 0.5f);
     float t = 1.0f - u;
     float sq = __builtin_amdgcn_sqrtf(t);
     float d = fmaf(u, k.om_a2, a2p);
+    // At the centre of a narrow lobe d cancels to ~a2, the weight ~1/d^2 amplifies the
+    // reference's float rounding of NoH^2 (about 1e-7/a2 per pair), and that rounding is
+    // not zero-mean there (1/sqrt of |half|^2 just below 4 lands on rounding ties).  Inside
+    // the lobe core the denominator is therefore recomputed with the reference's exact
+    // operation sequence.  Output tiles are small against the core, so the branch is
+    // nearly wave-uniform.
+    const bool core = d < k.core_thr;
+    if (__any(core)) {
+        F3 us = { (TAU & 1) ? -r[0] : r[0], (TAU & 2) ? -r[1] : r[1], (TAU & 4) ? -r[2] : r[2] };
+        float den = ref_ggx_denominator(us, n, -k.om_a2);
+        d = core ? den : d;
+    }
     float qd = (t - k.cutoff) * __builtin_amdgcn_rcpf(d);
     float f = (c * sq) * (qd * qd);
     bool ok = c > thr;
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
     uint32_t n_po, uint32_t ps2,
     uint32_t out_w, uint32_t tw, uint32_t first_block, uint32_t block_stride, uint32_t n_oct, uint32_t oct_local,
     uint32_t out_begin, uint32_t out_count,
-    float cutoff, float a2m1, float cmin, float theta_acc,
+    float cutoff, float a2m1, float cmin, float theta_acc, float core_thr,
     double* __restrict__ partial, unsigned long long* __restrict__ counts) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
     Texel c0 = octet_member(axis, oj, oi, 0, out_w, out_w);
     const F3 n = ref_normalize(ref_normal_from(c0.face, c0.x, c0.y, out_w, out_w));   // cube.cpp:242
     GoConst kc;
-    kc.cutoff = cutoff; kc.om_a2 = -a2m1; kc.cmin = cmin;
+    kc.cutoff = cutoff; kc.om_a2 = -a2m1; kc.cmin = cmin; kc.core_thr = core_thr;
     float a2p;
     {
         double eps = ((double)n.x * n.x + (double)n.y * n.y + (double)n.z * n.z) - 1.0;
@@ -291,21 +305,21 @@ __global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
                 auto eval_one = [&](const float4 (&src)[GO_REC], float c) {
                     float r[28];
                     unpack(src, r);
-                    go_body<0, COUNT>(c, r, thr[0], a2p, kc, acc, n_accepted);
+                    go_body<0, COUNT>(c, r, thr[0], a2p, kc, n, acc, n_accepted);
                 };
                 auto eval_all = [&](const float4 (&src)[GO_REC]) {
                     float r[28];
                     unpack(src, r);
                     const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
                     const float s1 = a + b, s2 = a - b;
-                    if (wmask & 1u)   go_body<0, COUNT>(s1 + cc, r, thr[0], a2p, kc, acc, n_accepted);
-                    if (wmask & 2u)   go_body<1, COUNT>(cc - s2, r, thr[1], a2p, kc, acc, n_accepted);
-                    if (wmask & 4u)   go_body<2, COUNT>(s2 + cc, r, thr[2], a2p, kc, acc, n_accepted);
-                    if (wmask & 8u)   go_body<3, COUNT>(cc - s1, r, thr[3], a2p, kc, acc, n_accepted);
-                    if (wmask & 16u)  go_body<4, COUNT>(s1 - cc, r, thr[4], a2p, kc, acc, n_accepted);
-                    if (wmask & 32u)  go_body<5, COUNT>(-s2 - cc, r, thr[5], a2p, kc, acc, n_accepted);
-                    if (wmask & 64u)  go_body<6, COUNT>(s2 - cc, r, thr[6], a2p, kc, acc, n_accepted);
-                    if (wmask & 128u) go_body<7, COUNT>(-s1 - cc, r, thr[7], a2p, kc, acc, n_accepted);
+                    if (wmask & 1u)   go_body<0, COUNT>(s1 + cc, r, thr[0], a2p, kc, n, acc, n_accepted);
+                    if (wmask & 2u)   go_body<1, COUNT>(cc - s2, r, thr[1], a2p, kc, n, acc, n_accepted);
+                    if (wmask & 4u)   go_body<2, COUNT>(s2 + cc, r, thr[2], a2p, kc, n, acc, n_accepted);
+                    if (wmask & 8u)   go_body<3, COUNT>(cc - s1, r, thr[3], a2p, kc, n, acc, n_accepted);
+                    if (wmask & 16u)  go_body<4, COUNT>(s1 - cc, r, thr[4], a2p, kc, n, acc, n_accepted);
+                    if (wmask & 32u)  go_body<5, COUNT>(-s2 - cc, r, thr[5], a2p, kc, n, acc, n_accepted);
+                    if (wmask & 64u)  go_body<6, COUNT>(s2 - cc, r, thr[6], a2p, kc, n, acc, n_accepted);
+                    if (wmask & 128u) go_body<7, COUNT>(-s1 - cc, r, thr[7], a2p, kc, n, acc, n_accepted);
                 };
                 load(ra, e0);
                 if (wmask == 1u) {
@@ -430,6 +444,7 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const float cmin = (float)fmax(0.0, 2.0 * cut - 1.0);
     const float theta_acc = (float)acos(fmin(1.0, fmax(-1.0, 2.0 * cut - 1.0)));
     const float a2m1 = pl.lv.alpha2 - 1.0f;
+    const float core_thr = ggx_core_threshold(pl.lv.alpha2);
     dim3 grid(pl.out_blocks, pl.n_slices);
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
     const uint32_t oct_count = pl.out_blocks * GO_THREADS;
@@ -437,11 +452,11 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     if (d_counts)
         ggx_oct_pairs<true><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
             ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
-            theta_acc, d_partial, d_counts);
+            theta_acc, core_thr, d_partial, d_counts);
     else
         ggx_oct_pairs<false><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
             ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
-            theta_acc, d_partial, d_counts);
+            theta_acc, core_thr, d_partial, d_counts);
     if (ev1) (void)hipEventRecord(ev1, stream);
     ggx_oct_final<<<dim3(pl.out_blocks, 8), GO_THREADS, 0, stream>>>(d_partial, pl.n_slices, out_w, pl.tw, first_block,
                                                             block_stride, n_oct, oct_count, out_begin, out_count,

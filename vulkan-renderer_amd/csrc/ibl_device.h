@@ -40,11 +40,18 @@ __device__ __forceinline__ float ref_dot(F3 a, F3 b) {
     return r;
 }
 
+// Correctly rounded float square root and quotient.  HIP's __fsqrt_rn is the native
+// (1 ulp) instruction despite its name, so these go through the IEEE paths: sqrtf and
+// '/' are correctly rounded when the file is built with
+// -fhip-fp32-correctly-rounded-divide-sqrt (the build sets it explicitly).
+__device__ __forceinline__ float ref_sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float ref_div(float a, float b) { return a / b; }
+
 // linear::normalize, include/linear.hpp:93-95,114-122: (1/sqrt(v.v)) * v with a
 // correctly rounded square root and division.
 __device__ __forceinline__ F3 ref_normalize(F3 v) {
 #pragma clang fp contract(off)
-    float inv = __fdiv_rn(1.0f, __fsqrt_rn(ref_dot(v, v)));
+    float inv = ref_div(1.0f, ref_sqrt(ref_dot(v, v)));
     F3 r = { inv * v.x, inv * v.y, inv * v.z };
     return r;
 }
@@ -63,6 +70,20 @@ __device__ __forceinline__ bool ref_cone_test(F3 u, F3 n, float cutoff) {
     float lhs = ch * ch;
     float rhs = cutoff * ref_dot(half, half);
     return lhs > rhs;
+}
+
+// The GGX denominator NoH^2*(a2-1)+1 exactly as the reference rounds it
+// (cube.cpp:267,279-280 with linear.hpp:93-122): half = u + n, NoH = dot(normalize(half), n),
+// every operation in float, no contraction, correctly rounded sqrt and division.
+__device__ __forceinline__ float ref_ggx_denominator(F3 u, F3 n, float a2m1) {
+#pragma clang fp contract(off)
+    F3 half = ref_add(u, n);
+    F3 hn = ref_normalize(half);
+    float noh = ref_dot(hn, n);
+    float den = noh * noh;
+    den = den * a2m1;
+    den = den + 1.0f;
+    return den;
 }
 
 // Output texel index (face, y, x order) -> unit direction, cube.cpp:97,242.

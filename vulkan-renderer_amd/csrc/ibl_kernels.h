@@ -45,6 +45,9 @@ struct GgxLevel {          // cube.cpp:161-175
 };
 GgxLevel ggx_level_params(uint32_t mip, uint32_t mips, uint32_t in_w, uint32_t in_h);
 uint32_t ggx_mip_levels(uint32_t top_w, uint32_t top_h, uint32_t min_size);
+// Denominator value below which a pair's GGX denominator is recomputed with the
+// reference's exact float sequence (0: never).  Only narrow lobes need it.
+float ggx_core_threshold(float alpha2);
 
 struct GgxPlan {
     GgxLevel lv;
@@ -92,6 +95,7 @@ hipError_t brdf_lut_launch(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sq
 
 hipError_t rgbe_decode_launch(const uint8_t* d_rgbe, float* d_rgba, uint32_t n, hipStream_t stream);
 hipError_t rgbe_encode_launch(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, hipStream_t stream);
+hipError_t texel_directions_launch(uint32_t w, uint32_t h, int normalized, float* d_out, hipStream_t stream);
 hipError_t downscale_launch(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, hipStream_t stream);
 
 }  // namespace ibl

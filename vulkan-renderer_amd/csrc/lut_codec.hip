@@ -11,6 +11,8 @@
 //     the jitter is a counter-based hash of (seed, cell, sample) or the stratum
 //     midpoint.
 // rgbe_decode / rgbe_encode   src/util.cpp:93-145, one texel per thread.
+// texel_directions   getNormalFrom + normalize (cube.cpp:31-50, linear.hpp:114-122), one
+//     texel per thread; the table both integrals start from.
 // downscale_box    cube.cpp:482-501, one output texel per thread, float sums in
 //     (row, column) order.
 #include "ibl_device.h"
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void rgbe_encode_k(const float4* __restrict__ 
         d = make_uchar4(0, 0, 0, 0);
     } else {
         int e;
-        float frac_mult = __fdiv_rn(256.0f * frexpf(m, &e), m);
+        float frac_mult = ref_div(256.0f * frexpf(m, &e), m);
         if (e > 127) {
             d = make_uchar4(255, 255, 255, 255);
         } else {
@@ -155,6 +157,25 @@ hipError_t rgbe_encode_launch(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, 
     return hipGetLastError();
 }
 
+// ---- texel directions ------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void texel_directions(uint32_t w, uint32_t h, uint32_t n, int normalized,
+                                                         float4* __restrict__ out) {
+    uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    const uint32_t f = o / (w * h), rem = o - f * (w * h);
+    const uint32_t y = rem / w, x = rem - y * w;
+    F3 d = ref_normal_from(f, x, y, w, h);
+    if (normalized) d = ref_normalize(d);
+    out[o] = make_float4(d.x, d.y, d.z, 0.0f);
+}
+
+hipError_t texel_directions_launch(uint32_t w, uint32_t h, int normalized, float* d_out, hipStream_t stream) {
+    const uint32_t n = w * h * 6;
+    if (n) texel_directions<<<(n + 255) / 256, 256, 0, stream>>>(w, h, n, normalized, (float4*)d_out);
+    return hipGetLastError();
+}
+
 // ---- box downscale --------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void downscale_box(const float4* __restrict__ env, uint32_t w, uint32_t ow,
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256) void downscale_box(const float4* __restrict__ 
             ax += t.x; ay += t.y; az += t.z;
         }
     }
-    const float inv = __fdiv_rn(1.0f, (float)(d * d));
+    const float inv = ref_div(1.0f, (float)(d * d));
     out[o] = make_float4(inv * ax, inv * ay, inv * az, 0.0f);
 }
 
