@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--input-downscale", type=int, default=1,
+                    help="c3/c5: box-filter the environment by this power of two first, as the tool's "
+                         "--input-downscale does (mip sizes still derive from the full size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -89,8 +92,11 @@ class Workload:
             self.in_w, self.min_size = (512, 16) if name == "c3" else (2048, 16)
             strip = vra.synth.hdr_environment(self.in_w, seed=args.seed)
             rgbe = t.from_numpy(strip).to(ibl.device)
-            self.env = ibl.rgbe_decode(rgbe).reshape(6, self.in_w, self.in_w, 4).contiguous()
-            self.mips = ibl.ggx_mip_levels(self.in_w, self.in_w, self.min_size)
+            full = ibl.rgbe_decode(rgbe).reshape(6, self.in_w, self.in_w, 4).contiguous()
+            self.down = args.input_downscale
+            self.env = ibl.downscale(full, self.down) if self.down > 1 else full   # cube.cpp:472-504
+            self.env_w = self.in_w // self.down
+            self.mips = ibl.ggx_mip_levels(self.in_w, self.in_w, self.min_size)    # cube.cpp:473-474,513
             self.levels = []
             for m in range(1, self.mips + 1):
                 ow = self.in_w >> m
@@ -115,18 +121,21 @@ class Workload:
             self.flop_per_launch = frac * (FLOP_PER_GGX_ACCEPTED * lv1["accepted"]
                                            + FLOP_PER_GGX_REJECTED * (lv1["tested"] - lv1["accepted"]))
             self.kernel = "ggx_oct_pairs (level 1)"
-            self.desc = ("C%s: GGX prefilter chain of a %dx%d/face environment, %d levels, --input-downscale 1; "
+            self.desc = ("C%s: GGX prefilter chain of a %dx%d/face environment, %d levels, --input-downscale %d; "
                          "samples = in-patch texel tests (%.3g tested, %.3g accepted)"
-                         % (name[1], self.in_w, self.in_w, self.mips, tested, accepted))
-            self.bytes_per_launch = 32 * 6 * self.in_w * self.in_w + 16 * lv1["count"]
+                         % (name[1], self.in_w, self.in_w, self.mips, self.down, tested, accepted))
+            self.bytes_per_launch = 32 * 6 * self.env_w * self.env_w + 16 * lv1["count"]
             if name == "c5":
-                # plus the Lambertian irradiance of the 1024x1024/face (2x box-filtered) environment
-                self.lam_env = ibl.downscale(self.env, 2)
+                # plus the Lambertian irradiance of the 1024x1024/face (2x box-filtered) environment,
+                # or of the downscaled one when --input-downscale is coarser than that
+                lam_down = max(2, self.down)
+                self.lam_env = ibl.downscale(full, lam_down)
+                lam_in = self.in_w // lam_down
                 self.lam_w = 128
                 self.lam_out = t.zeros((6, self.lam_w, self.lam_w, 4), dtype=t.float32, device=ibl.device)
-                pairs = 6 * self.lam_w * self.lam_w * 6 * 1024 * 1024
+                pairs = 6 * self.lam_w * self.lam_w * 6 * lam_in * lam_in
                 self.samples += pairs
-                self.desc += "; + Lambertian 1024x1024/face -> 128x128/face (%.3g pairs)" % pairs
+                self.desc += "; + Lambertian %dx%d/face -> 128x128/face (%.3g pairs)" % (lam_in, lam_in, pairs)
         elif name == "c2":
             self.s = 32
             self.n_cells = 256 * 256
