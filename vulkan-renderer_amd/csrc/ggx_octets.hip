@@ -38,7 +38,10 @@
 
 namespace ibl {
 
-constexpr int GO_THREADS = 256;
+constexpr int GO_THREADS = 256;         // output octets per block: the unit of sharding
+#ifndef GO_WG
+#define GO_WG 64                        // threads per workgroup of ggx_oct_pairs (waves are independent)
+#endif
 constexpr int GO_REC = 7;              // float4 per texel-octet record
 constexpr int GO_FLUSH = 64;           // records per FP32 chunk when all 8 patterns are live
 
@@ -151,7 +154,7 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
 #define GO_MIN_WAVES 4   // 128 registers: a few spills, but 4 waves per SIMD measured faster than 3
 #endif
 template <bool COUNT>
-__global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
+__global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn,
     uint32_t n_po, uint32_t ps2,
     uint32_t out_w, uint32_t tw, uint32_t first_block, uint32_t block_stride, uint32_t n_oct, uint32_t oct_local,
@@ -161,9 +164,11 @@ __global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     // This call owns the 256-octet blocks first_block, first_block + block_stride, ...
-    // of the tile-major octet order; lo indexes its partial sums.
-    const uint32_t lo = blockIdx.x * GO_THREADS + tid;
-    const uint32_t gidx = (blockIdx.x * block_stride + first_block) * GO_THREADS + tid;
+    // of the tile-major octet order; lo indexes its partial sums.  A workgroup is
+    // GO_WG / 64 of the four waves of a block.
+    const uint32_t wv = blockIdx.x * (GO_WG / 64) + (tid >> 6);
+    const uint32_t lo = wv * 64 + lane;
+    const uint32_t gidx = ((wv >> 2) * block_stride + first_block) * GO_THREADS + (wv & 3u) * 64 + lane;
     const bool lane_valid = gidx < n_oct;
     const uint32_t oct_count = oct_local;
     const uint32_t hw = out_w / 2;
@@ -376,6 +381,27 @@ __global__ __launch_bounds__(GO_THREADS, GO_MIN_WAVES) void ggx_oct_pairs(
     }
 }
 
+// First stage of the slice sum when a level has many slices: group g adds its run of
+// consecutive slices, in order, into one more set of partial sums.  One thread per
+// (output octet, member, group).
+__global__ __launch_bounds__(256) void ggx_oct_reduce(const double* __restrict__ partial, uint32_t n_slices,
+                                                       uint32_t per_group, uint32_t n_oct, uint32_t first_block,
+                                                       uint32_t block_stride, uint32_t oct_count,
+                                                       double* __restrict__ reduced) {
+    const uint32_t lo = blockIdx.x * GO_THREADS + threadIdx.x;
+    const uint32_t gidx = (blockIdx.x * block_stride + first_block) * GO_THREADS + threadIdx.x;
+    const uint32_t m = blockIdx.y, g = blockIdx.z;
+    if (gidx >= n_oct) return;
+    const uint32_t s0 = g * per_group, s1 = min(n_slices, s0 + per_group);
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (uint32_t sl = s0; sl < s1; sl++) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) v[k] += partial[((size_t)sl * 32 + (m * 4 + k)) * oct_count + lo];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) reduced[((size_t)g * 32 + (m * 4 + k)) * oct_count + lo] = v[k];
+}
+
 // One thread per (output octet, member): coalesced over the octet index.
 __global__ __launch_bounds__(256) void ggx_oct_final(const double* __restrict__ partial, uint32_t n_slices,
                                                       uint32_t out_w, uint32_t tw, uint32_t first_block,
@@ -417,7 +443,19 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     // slices come from the level geometry only (range/shard independence)
     const uint32_t n_oct_level = 3 * (out_w / 2) * (out_w / 2);
     const uint32_t blocks_level = (n_oct_level + GO_THREADS - 1) / GO_THREADS;
-    uint32_t want = (3072 + blocks_level - 1) / blocks_level;
+    // Enough waves that an eighth of the level (one of 8 GPUs) still fills a GPU four
+    // times over (4096 wave slots each): 131072, measured to be the best choice on one GPU
+    // as well.  Large levels get up to twice that, as far as their work can carry the
+    // partial sums (every (wave, slice) writes 64 x 32 doubles; that traffic is kept to a
+    // few per cent of the estimated run time).
+    const double cmin = fmax(0.0, 2.0 * (double)pl.lv.cutoff - 1.0);
+    const double cone = 0.5 * (1.0 - cmin);                              // accepted share of the sphere
+    const double wave_records = (double)n_oct_level / 64.0 * (double)pl.n_po * ps * ps * 8.0 * cone;
+    const double seconds = wave_records * 70e-9 / 1024.0;                // ~70 ns per wave, record and pattern per SIMD
+    double waves = 0.04 * seconds * 1.5e12 / 16384.0;
+    if (const char* e = getenv("IBL_GGX_WAVES")) waves = atof(e);        // tuning knob
+    waves = fmin(fmax(waves, 131072.0), 262144.0);
+    uint32_t want = (uint32_t)ceil(waves / (4.0 * blocks_level));
     uint32_t max_slices = pl.n_po;                           // at least one patch octet per slice
     if (max_slices == 0) max_slices = 1;
     uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
@@ -426,7 +464,11 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     // blocks first_block, first_block + stride, ... below blocks_level
     pl.out_blocks = first_block < blocks_level ? (blocks_level - first_block + block_stride - 1) / block_stride : 0;
     const uint32_t oct_count = pl.out_blocks * GO_THREADS;
-    pl.partial_bytes = (size_t)pl.n_slices * 32 * oct_count * sizeof(double);
+    // many slices are summed in two stages (fixed grouping, so still one summation order)
+    pl.reduce_groups = pl.n_slices > 64 ? (pl.n_slices + 31) / 32 : 1;
+    if (pl.reduce_groups > 64) pl.reduce_groups = 64;
+    const uint32_t stage2 = pl.reduce_groups > 1 ? pl.reduce_groups : 0;
+    pl.partial_bytes = (size_t)(pl.n_slices + stage2) * 32 * oct_count * sizeof(double);
     pl.rec_bytes = (size_t)pl.n_po * ps * ps * GO_REC * sizeof(float4);
     pl.pn_bytes = (size_t)pl.n_po * sizeof(float4);
     return pl;
@@ -445,20 +487,30 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const float theta_acc = (float)acos(fmin(1.0, fmax(-1.0, 2.0 * cut - 1.0)));
     const float a2m1 = pl.lv.alpha2 - 1.0f;
     const float core_thr = ggx_core_threshold(pl.lv.alpha2);
-    dim3 grid(pl.out_blocks, pl.n_slices);
+    dim3 grid(pl.out_blocks * (GO_THREADS / GO_WG), pl.n_slices);
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
     const uint32_t oct_count = pl.out_blocks * GO_THREADS;
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (d_counts)
-        ggx_oct_pairs<true><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
+        ggx_oct_pairs<true><<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
             ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, core_thr, d_partial, d_counts);
     else
-        ggx_oct_pairs<false><<<grid, GO_THREADS, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
+        ggx_oct_pairs<false><<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
             ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, core_thr, d_partial, d_counts);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    ggx_oct_final<<<dim3(pl.out_blocks, 8), GO_THREADS, 0, stream>>>(d_partial, pl.n_slices, out_w, pl.tw, first_block,
+    const double* d_sums = d_partial;
+    uint32_t n_sums = pl.n_slices;
+    if (pl.reduce_groups > 1) {
+        double* d_reduced = d_partial + (size_t)pl.n_slices * 32 * oct_count;
+        const uint32_t per_group = (pl.n_slices + pl.reduce_groups - 1) / pl.reduce_groups;
+        ggx_oct_reduce<<<dim3(pl.out_blocks, 8, pl.reduce_groups), GO_THREADS, 0, stream>>>(
+            d_partial, pl.n_slices, per_group, n_oct, first_block, block_stride, oct_count, d_reduced);
+        d_sums = d_reduced;
+        n_sums = pl.reduce_groups;
+    }
+    ggx_oct_final<<<dim3(pl.out_blocks, 8), GO_THREADS, 0, stream>>>(d_sums, n_sums, out_w, pl.tw, first_block,
                                                             block_stride, n_oct, oct_count, out_begin, out_count,
                                                             (float4*)d_out);
     return hipGetLastError();

@@ -75,8 +75,9 @@ struct GgxOctPlan {
     uint32_t tw;              // edge of the output tile used for octet numbering
     uint32_t po_per_slice;
     uint32_t n_slices;
+    uint32_t reduce_groups;   // > 1: the slices are summed in this many groups first
     uint32_t out_blocks;
-    size_t partial_bytes;     // [slice][32][out_blocks*256] double
+    size_t partial_bytes;     // [slice (+ group)][32][out_blocks*256] double
     size_t rec_bytes;         // 7 float4 per input texel octet
     size_t pn_bytes;          // float4 per patch octet
 };
