@@ -41,11 +41,15 @@ def main():
             ow = in_w >> m
             o = torch.zeros((6, ow, ow, 4), device="cuda")
             jobs.append(("ggx level %d" % m, lambda r, n, ow=ow, m=m, o=o: ibl.ggx_level_shard(env, ow, m, mips, r, n, out=o)))
+    only = os.environ.get("SHARD_LEVELS")          # e.g. "1,2": restrict a GGX chain to these levels
+    if only and wl != "c4":
+        jobs = [jobs[int(v) - 1] for v in only.split(",")]
+    ns = tuple(int(v) for v in os.environ.get("SHARD_NS", "1,2,4,8").split(","))
     totals = {}
     for name, fn in jobs:
         base = None
-        for n in (1, 2, 4, 8):
-            ranks = range(n) if n <= 4 else (0, 3, 7)
+        for n in ns:
+            ranks = range(n) if (n <= 4 or os.environ.get("SHARD_ALL")) else (0, 3, 7)
             ts, ks = [], []
             for r in ranks:
                 ts.append(timed(lambda: fn(r, n), reps=2 if wl == "c5" else 3))
@@ -54,12 +58,14 @@ def main():
                 except vra.capi.IblError:      # this rank owns no block of the level
                     ks.append(0.0)
             worst = max(ts)
-            base = worst if n == 1 else base
+            base = worst * n if base is None else base
             totals[n] = totals.get(n, 0.0) + worst
             print("%-14s N=%d  slowest shard %9.3f ms  (ideal %9.3f)  efficiency %.3f   main kernel alone %9.3f ms"
                   % (name, n, worst, base / n, base / n / worst, max(ks)), flush=True)
-    for n in (1, 2, 4, 8):
-        print("total N=%d  %9.3f ms  efficiency %.3f" % (n, totals[n], totals[1] / n / totals[n]))
+            if os.environ.get("SHARD_ALL"):
+                print("    per shard:", " ".join("%.2f" % t for t in ts), " sum %.2f" % sum(ts), flush=True)
+    for n in ns:
+        print("total N=%d  %9.3f ms  efficiency %.3f" % (n, totals[n], totals[ns[0]] * ns[0] / n / totals[n]))
 
 
 if __name__ == "__main__":

@@ -305,13 +305,13 @@ int ggx_counts_buffer(hipStream_t s, unsigned long long** d_counts) {
     return IBL_OK;
 }
 
-// Octet kernel over the 256-octet blocks first_block, first_block + block_stride, ...,
+// Octet kernel over the 64-octet units first_block, first_block + block_stride, ...,
 // writing the member texels inside [out_begin, out_begin+out_count).
 int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
                    uint32_t first_block, uint32_t block_stride, uint32_t out_begin, uint32_t out_count, float* d_out,
                    hipStream_t s) {
     ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, first_block, block_stride);
-    if (pl.out_blocks == 0) { g.timed_valid = false; return IBL_OK; }
+    if (pl.out_units == 0) { g.timed_valid = false; return IBL_OK; }
     if (int rc = ensure(g.a, pl.rec_bytes)) return rc;
     if (int rc = ensure(g.pn, pl.pn_bytes)) return rc;
     if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
@@ -374,12 +374,12 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
         return ibl_ggx_level_dev(d_env, in_w, in_h, out_w, out_h, mip_level, mip_levels, begin, count, d_out, stream);
     }
     // GGX cost per output tile varies over the cube (patches near a face centre subtend
-    // more solid angle), so shards take every n_shards-th block of 256 octets.
+    // more solid angle), so shards take every n_shards-th unit of 64 octets (one wave's worth).
     const uint32_t n_patches = 6 * (in_w / patch) * (in_h / patch);
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
-    const uint32_t n_blocks = (n_oct + 255) / 256;
-    const uint32_t mine = shard < n_blocks ? (n_blocks - shard + n_shards - 1) / n_shards : 0;
-    g.last_counts[0] = (uint64_t)mine * 256 * 8 * n_patches;
+    const uint32_t n_units = (n_oct + 63) / 64;
+    const uint32_t mine = shard < n_units ? (n_units - shard + n_shards - 1) / n_shards : 0;
+    g.last_counts[0] = (uint64_t)mine * 64 * 8 * n_patches;
     g.last_counts[1] = g.last_counts[2] = 0;
     g.counts_pending = false;
     if (mine == 0) { g.timed_valid = false; return IBL_OK; }

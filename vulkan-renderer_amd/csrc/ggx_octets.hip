@@ -38,7 +38,8 @@
 
 namespace ibl {
 
-constexpr int GO_THREADS = 256;         // output octets per block: the unit of sharding
+constexpr int GO_THREADS = 256;         // threads per workgroup of the small kernels
+constexpr int GO_UNIT = 64;             // output octets per wave: the unit of sharding
 #ifndef GO_WG
 #define GO_WG 64                        // threads per workgroup of ggx_oct_pairs (waves are independent)
 #endif
@@ -61,6 +62,12 @@ __device__ __forceinline__ void go_decode(uint32_t g, uint32_t hw, uint32_t tw, 
     const uint32_t ty = trem / tpr, tx = trem - ty * tpr;
     oj = ty * tw + ly;
     oi = tx * tw + lx;
+}
+
+// A call owns the 64-octet units first_unit, first_unit + unit_stride, ... of the
+// tile-major octet order; lo indexes its own octets (and its partial sums).
+__device__ __forceinline__ uint32_t go_global(uint32_t lo, uint32_t first_unit, uint32_t unit_stride) {
+    return ((lo / GO_UNIT) * unit_stride + first_unit) * GO_UNIT + (lo % GO_UNIT);
 }
 
 __global__ __launch_bounds__(256) void ggx_oct_prep(const float4* __restrict__ env, uint32_t w, uint32_t ps,
@@ -163,12 +170,10 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
     double* __restrict__ partial, unsigned long long* __restrict__ counts) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    // This call owns the 256-octet blocks first_block, first_block + block_stride, ...
-    // of the tile-major octet order; lo indexes its partial sums.  A workgroup is
-    // GO_WG / 64 of the four waves of a block.
-    const uint32_t wv = blockIdx.x * (GO_WG / 64) + (tid >> 6);
-    const uint32_t lo = wv * 64 + lane;
-    const uint32_t gidx = ((wv >> 2) * block_stride + first_block) * GO_THREADS + (wv & 3u) * 64 + lane;
+    const uint32_t wv = blockIdx.x * (GO_WG / 64) + (tid >> 6);      // this wave's unit among the call's
+    const uint32_t lo = wv * GO_UNIT + lane;
+    if (lo >= oct_local) return;                                     // whole wave: no barrier below
+    const uint32_t gidx = go_global(lo, first_block, block_stride);
     const bool lane_valid = gidx < n_oct;
     const uint32_t oct_count = oct_local;
     const uint32_t hw = out_w / 2;
@@ -389,7 +394,8 @@ __global__ __launch_bounds__(256) void ggx_oct_reduce(const double* __restrict__
                                                        uint32_t block_stride, uint32_t oct_count,
                                                        double* __restrict__ reduced) {
     const uint32_t lo = blockIdx.x * GO_THREADS + threadIdx.x;
-    const uint32_t gidx = (blockIdx.x * block_stride + first_block) * GO_THREADS + threadIdx.x;
+    if (lo >= oct_count) return;
+    const uint32_t gidx = go_global(lo, first_block, block_stride);
     const uint32_t m = blockIdx.y, g = blockIdx.z;
     if (gidx >= n_oct) return;
     const uint32_t s0 = g * per_group, s1 = min(n_slices, s0 + per_group);
@@ -408,7 +414,8 @@ __global__ __launch_bounds__(256) void ggx_oct_final(const double* __restrict__ 
                                                       uint32_t block_stride, uint32_t n_oct, uint32_t oct_count,
                                                       uint32_t out_begin, uint32_t out_count, float4* __restrict__ out) {
     const uint32_t lo = blockIdx.x * GO_THREADS + threadIdx.x;
-    const uint32_t gidx = (blockIdx.x * block_stride + first_block) * GO_THREADS + threadIdx.x;
+    if (lo >= oct_count) return;
+    const uint32_t gidx = go_global(lo, first_block, block_stride);
     const uint32_t m = blockIdx.y;
     if (gidx >= n_oct) return;
     uint32_t axis, oj, oi;
@@ -442,7 +449,7 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     pl.tw = go_tile_edge(out_w / 2);
     // slices come from the level geometry only (range/shard independence)
     const uint32_t n_oct_level = 3 * (out_w / 2) * (out_w / 2);
-    const uint32_t blocks_level = (n_oct_level + GO_THREADS - 1) / GO_THREADS;
+    const uint32_t units_level = (n_oct_level + GO_UNIT - 1) / GO_UNIT;      // one wave each per slice
     // Enough waves that an eighth of the level (one of 8 GPUs) still fills a GPU four
     // times over (4096 wave slots each): 131072, measured to be the best choice on one GPU
     // as well.  Large levels get up to twice that, as far as their work can carry the
@@ -455,15 +462,15 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     double waves = 0.04 * seconds * 1.5e12 / 16384.0;
     if (const char* e = getenv("IBL_GGX_WAVES")) waves = atof(e);        // tuning knob
     waves = fmin(fmax(waves, 131072.0), 262144.0);
-    uint32_t want = (uint32_t)ceil(waves / (4.0 * blocks_level));
+    uint32_t want = (uint32_t)ceil(waves / (double)units_level);
     uint32_t max_slices = pl.n_po;                           // at least one patch octet per slice
     if (max_slices == 0) max_slices = 1;
     uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
     pl.po_per_slice = (pl.n_po + slices - 1) / slices;
     pl.n_slices = slices;
-    // blocks first_block, first_block + stride, ... below blocks_level
-    pl.out_blocks = first_block < blocks_level ? (blocks_level - first_block + block_stride - 1) / block_stride : 0;
-    const uint32_t oct_count = pl.out_blocks * GO_THREADS;
+    // units first_block, first_block + stride, ... below units_level
+    pl.out_units = first_block < units_level ? (units_level - first_block + block_stride - 1) / block_stride : 0;
+    const uint32_t oct_count = pl.out_units * GO_UNIT;
     // many slices are summed in two stages (fixed grouping, so still one summation order)
     pl.reduce_groups = pl.n_slices > 64 ? (pl.n_slices + 31) / 32 : 1;
     if (pl.reduce_groups > 64) pl.reduce_groups = 64;
@@ -487,9 +494,10 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const float theta_acc = (float)acos(fmin(1.0, fmax(-1.0, 2.0 * cut - 1.0)));
     const float a2m1 = pl.lv.alpha2 - 1.0f;
     const float core_thr = ggx_core_threshold(pl.lv.alpha2);
-    dim3 grid(pl.out_blocks * (GO_THREADS / GO_WG), pl.n_slices);
+    dim3 grid((pl.out_units * GO_UNIT + GO_WG - 1) / GO_WG, pl.n_slices);
+    const uint32_t small_blocks = (pl.out_units * GO_UNIT + GO_THREADS - 1) / GO_THREADS;
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
-    const uint32_t oct_count = pl.out_blocks * GO_THREADS;
+    const uint32_t oct_count = pl.out_units * GO_UNIT;
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (d_counts)
         ggx_oct_pairs<true><<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
@@ -505,12 +513,12 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     if (pl.reduce_groups > 1) {
         double* d_reduced = d_partial + (size_t)pl.n_slices * 32 * oct_count;
         const uint32_t per_group = (pl.n_slices + pl.reduce_groups - 1) / pl.reduce_groups;
-        ggx_oct_reduce<<<dim3(pl.out_blocks, 8, pl.reduce_groups), GO_THREADS, 0, stream>>>(
+        ggx_oct_reduce<<<dim3(small_blocks, 8, pl.reduce_groups), GO_THREADS, 0, stream>>>(
             d_partial, pl.n_slices, per_group, n_oct, first_block, block_stride, oct_count, d_reduced);
         d_sums = d_reduced;
         n_sums = pl.reduce_groups;
     }
-    ggx_oct_final<<<dim3(pl.out_blocks, 8), GO_THREADS, 0, stream>>>(d_sums, n_sums, out_w, pl.tw, first_block,
+    ggx_oct_final<<<dim3(small_blocks, 8), GO_THREADS, 0, stream>>>(d_sums, n_sums, out_w, pl.tw, first_block,
                                                             block_stride, n_oct, oct_count, out_begin, out_count,
                                                             (float4*)d_out);
     return hipGetLastError();

@@ -76,13 +76,13 @@ struct GgxOctPlan {
     uint32_t po_per_slice;
     uint32_t n_slices;
     uint32_t reduce_groups;   // > 1: the slices are summed in this many groups first
-    uint32_t out_blocks;
-    size_t partial_bytes;     // [slice (+ group)][32][out_blocks*256] double
+    uint32_t out_units;       // 64-octet units this call covers
+    size_t partial_bytes;     // [slice (+ group)][32][out_units*64] double
     size_t rec_bytes;         // 7 float4 per input texel octet
     size_t pn_bytes;          // float4 per patch octet
 };
 bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
-// The call covers the 256-octet blocks first_block, first_block + block_stride, ...
+// The call covers the 64-octet units first_block, first_block + block_stride, ... (tile-major octet order)
 GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t first_block,
                         uint32_t block_stride);
 hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_w,
