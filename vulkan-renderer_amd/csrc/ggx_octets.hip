@@ -44,6 +44,7 @@ constexpr int GO_UNIT = 64;             // output octets per wave: the unit of s
 #define GO_WG 64                        // threads per workgroup of ggx_oct_pairs (waves are independent)
 #endif
 constexpr int GO_REC = 7;              // float4 per texel-octet record
+constexpr int GO_SUMS = 25;             // doubles per (slice, output octet): 8 members x RGB + the weight sum
 constexpr int GO_FLUSH = 64;           // records per FP32 chunk when all 8 patterns are live
 
 // Output octets are numbered tile-major: tiles of tw x tw canonical positions.
@@ -370,12 +371,15 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
         }
     }
 
+    // The 8 members of an octet see the same weights (each pairs with input member
+    // so ^ tau), so their weight sums are one and the same number: stored once.
     if (lane_valid) {
 #pragma unroll
         for (int m = 0; m < 8; m++)
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                partial[((size_t)blockIdx.y * 32 + (m * 4 + k)) * oct_count + lo] = dacc[m][k];
+            for (int k = 1; k < 4; k++)
+                partial[((size_t)blockIdx.y * GO_SUMS + (m * 3 + k - 1)) * oct_count + lo] = dacc[m][k];
+        partial[((size_t)blockIdx.y * GO_SUMS + 24) * oct_count + lo] = dacc[0][0];
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -399,13 +403,13 @@ __global__ __launch_bounds__(256) void ggx_oct_reduce(const double* __restrict__
     const uint32_t m = blockIdx.y, g = blockIdx.z;
     if (gidx >= n_oct) return;
     const uint32_t s0 = g * per_group, s1 = min(n_slices, s0 + per_group);
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    // m < 8: the member's RGB sums; m == 8: the octet's weight sum
+    const uint32_t j0 = m < 8 ? m * 3 : 24, nj = m < 8 ? 3 : 1;
+    double v[3] = {0.0, 0.0, 0.0};
     for (uint32_t sl = s0; sl < s1; sl++) {
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) v[k] += partial[((size_t)sl * 32 + (m * 4 + k)) * oct_count + lo];
+        for (uint32_t k = 0; k < nj; k++) v[k] += partial[((size_t)sl * GO_SUMS + (j0 + k)) * oct_count + lo];
     }
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) reduced[((size_t)g * 32 + (m * 4 + k)) * oct_count + lo] = v[k];
+    for (uint32_t k = 0; k < nj; k++) reduced[((size_t)g * GO_SUMS + (j0 + k)) * oct_count + lo] = v[k];
 }
 
 // One thread per (output octet, member): coalesced over the octet index.
@@ -423,13 +427,14 @@ __global__ __launch_bounds__(256) void ggx_oct_final(const double* __restrict__ 
     Texel t = octet_member(axis, oj, oi, m, out_w, out_w);
     const uint32_t o = (t.face * out_w + t.y) * out_w + t.x;
     if (o - out_begin >= out_count) return;
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    double v[3] = {0.0, 0.0, 0.0}, w = 0.0;
     for (uint32_t sl = 0; sl < n_slices; sl++) {
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) v[k] += partial[((size_t)sl * 32 + (m * 4 + k)) * oct_count + lo];
+        for (uint32_t k = 0; k < 3; k++) v[k] += partial[((size_t)sl * GO_SUMS + (m * 3 + k)) * oct_count + lo];
+        w += partial[((size_t)sl * GO_SUMS + 24) * oct_count + lo];
     }
-    double inv = 1.0 / v[0];   // cube.cpp:305 via linear.hpp:93-95
-    out[o] = make_float4((float)(inv * v[1]), (float)(inv * v[2]), (float)(inv * v[3]), 0.0f);
+    double inv = 1.0 / w;   // cube.cpp:305 via linear.hpp:93-95
+    out[o] = make_float4((float)(inv * v[0]), (float)(inv * v[1]), (float)(inv * v[2]), 0.0f);
 }
 
 // ---- launch plan -----------------------------------------------------------
@@ -453,13 +458,13 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     // Enough waves that an eighth of the level (one of 8 GPUs) still fills a GPU four
     // times over (4096 wave slots each): 131072, measured to be the best choice on one GPU
     // as well.  Large levels get up to twice that, as far as their work can carry the
-    // partial sums (every (wave, slice) writes 64 x 32 doubles; that traffic is kept to a
+    // partial sums (every (wave, slice) writes 64 x 25 doubles; that traffic is kept to a
     // few per cent of the estimated run time).
     const double cmin = fmax(0.0, 2.0 * (double)pl.lv.cutoff - 1.0);
     const double cone = 0.5 * (1.0 - cmin);                              // accepted share of the sphere
     const double wave_records = (double)n_oct_level / 64.0 * (double)pl.n_po * ps * ps * 8.0 * cone;
     const double seconds = wave_records * 70e-9 / 1024.0;                // ~70 ns per wave, record and pattern per SIMD
-    double waves = 0.04 * seconds * 1.5e12 / 16384.0;
+    double waves = 0.04 * seconds * 1.5e12 / (64.0 * GO_SUMS * 8.0);
     if (const char* e = getenv("IBL_GGX_WAVES")) waves = atof(e);        // tuning knob
     waves = fmin(fmax(waves, 131072.0), 262144.0);
     uint32_t want = (uint32_t)ceil(waves / (double)units_level);
@@ -475,7 +480,7 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     pl.reduce_groups = pl.n_slices > 64 ? (pl.n_slices + 31) / 32 : 1;
     if (pl.reduce_groups > 64) pl.reduce_groups = 64;
     const uint32_t stage2 = pl.reduce_groups > 1 ? pl.reduce_groups : 0;
-    pl.partial_bytes = (size_t)(pl.n_slices + stage2) * 32 * oct_count * sizeof(double);
+    pl.partial_bytes = (size_t)(pl.n_slices + stage2) * GO_SUMS * oct_count * sizeof(double);
     pl.rec_bytes = (size_t)pl.n_po * ps * ps * GO_REC * sizeof(float4);
     pl.pn_bytes = (size_t)pl.n_po * sizeof(float4);
     return pl;
@@ -511,9 +516,9 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const double* d_sums = d_partial;
     uint32_t n_sums = pl.n_slices;
     if (pl.reduce_groups > 1) {
-        double* d_reduced = d_partial + (size_t)pl.n_slices * 32 * oct_count;
+        double* d_reduced = d_partial + (size_t)pl.n_slices * GO_SUMS * oct_count;
         const uint32_t per_group = (pl.n_slices + pl.reduce_groups - 1) / pl.reduce_groups;
-        ggx_oct_reduce<<<dim3(small_blocks, 8, pl.reduce_groups), GO_THREADS, 0, stream>>>(
+        ggx_oct_reduce<<<dim3(small_blocks, 9, pl.reduce_groups), GO_THREADS, 0, stream>>>(
             d_partial, pl.n_slices, per_group, n_oct, first_block, block_stride, oct_count, d_reduced);
         d_sums = d_reduced;
         n_sums = pl.reduce_groups;

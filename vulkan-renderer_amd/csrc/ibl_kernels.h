@@ -77,7 +77,7 @@ struct GgxOctPlan {
     uint32_t n_slices;
     uint32_t reduce_groups;   // > 1: the slices are summed in this many groups first
     uint32_t out_units;       // 64-octet units this call covers
-    size_t partial_bytes;     // [slice (+ group)][32][out_units*64] double
+    size_t partial_bytes;     // [slice (+ group)][25][out_units*64] double
     size_t rec_bytes;         // 7 float4 per input texel octet
     size_t pn_bytes;          // float4 per patch octet
 };
