@@ -159,7 +159,8 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
 // with wave-uniform addresses (scalar loads through the scalar data cache) and feed
 // the VALU as scalar operands.
 #ifndef GO_MIN_WAVES
-#define GO_MIN_WAVES 4   // 128 registers: a few spills, but 4 waves per SIMD measured faster than 3
+#define GO_MIN_WAVES 6   // 85 registers: the rarely touched FP64 sums spill to scratch, yet 6 waves per
+                         // SIMD measured 7 % faster than 4 or 5 (more scalar-load latency hidden); 7 is slower
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
