@@ -67,6 +67,7 @@ class Workload:
         import vulkan_renderer_amd as vra
         from vulkan_renderer_amd import sharding
         self.name, self.ibl, self.rank, self.world, self.dist = name, ibl, rank, world, dist
+        self.host_staged_collectives = world > 1 and dist.get_backend() == "gloo"
         self.sharding = sharding
         t = ibl.torch
         self.kernel_ms = []
@@ -148,6 +149,14 @@ class Workload:
             self.bytes_per_launch = 8 * self.count
         self.np = np
 
+    def _all_reduce(self, t):
+        # gloo stages CUDA tensors through the host; with kernels that use scratch memory
+        # still in flight on the same device its copy never completes, so the rehearsal
+        # backend drains the stream first.  RCCL orders itself behind the stream.
+        if self.host_staged_collectives:
+            self.ibl.torch.cuda.synchronize()
+        self.dist.all_reduce(t)
+
     def step(self):
         ibl, d = self.ibl, self.dist
         if self.name in ("c1", "c4"):
@@ -156,14 +165,14 @@ class Workload:
             ibl.lambertian_shard(self.env, self.out_w, self.rank, self.world, out=self.out)
             self.kernel_ms.append(ibl.last_kernel_ms() if self.count else 0.0)
             if self.world > 1:
-                d.all_reduce(self.out)
+                self._all_reduce(self.out)
         elif self.name in ("c3", "c5"):
             if self.name == "c5":
                 if self.world > 1:
                     self.lam_out.zero_()
                 ibl.lambertian_shard(self.lam_env, self.lam_w, self.rank, self.world, out=self.lam_out)
                 if self.world > 1:
-                    d.all_reduce(self.lam_out)
+                    self._all_reduce(self.lam_out)
             for lv in self.levels:
                 if self.world > 1:
                     lv["out"].zero_()
@@ -171,7 +180,7 @@ class Workload:
                 if lv["m"] == 1:
                     self.kernel_ms.append(ibl.last_kernel_ms() if lv["count"] else 0.0)
                 if self.world > 1:
-                    d.all_reduce(lv["out"])
+                    self._all_reduce(lv["out"])
         else:
             ibl.brdf_lut(256, 256, self.s, seed=1, cell_begin=self.begin, cell_count=self.count, out=self.out)
             self.kernel_ms.append(ibl.last_kernel_ms() if self.count else 0.0)
