@@ -90,14 +90,32 @@ def test_output_ranges_are_independent(orc):
     np.testing.assert_array_equal(orc.lambertian(env, 8, faithful=True), full)
 
 
+def _pin_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_pins", os.path.join(GOLDEN, "make_oracle_pins.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def test_oracle_regression_pins(orc):
-    """Outputs of the oracle on a seeded 16x16 environment, committed by
+    """Outputs of the oracle on nine seeded environments, committed by
     tests/golden/make_oracle_pins.py: guards the checker against silent edits."""
-    pins = np.load(os.path.join(GOLDEN, "oracle_pins_16.npz"))
-    env = decode_strip(orc, pins["rgbe"])
-    np.testing.assert_array_equal(orc.lambertian(env, 8), pins["lambertian8"])
-    np.testing.assert_array_equal(orc.ggx_level(env, 8, 8, 1, 1), pins["ggx8_r1"])
-    np.testing.assert_array_equal(orc.rgbe_encode(pins["lambertian8"]), pins["lambertian8_rgbe"])
+    mk = _pin_cases()
+    pins = np.load(os.path.join(GOLDEN, "oracle_pins.npz"))
+    np.testing.assert_array_equal(mk.environment("hdr", 16), pins["hdr16_rgbe"])
+    n = 0
+    for kind, w in mk.CASES:
+        env = decode_strip(orc, mk.environment(kind, w))
+        size = mk.cubemap_size(w)
+        key = "%s%d" % (kind, w)
+        np.testing.assert_array_equal(orc.lambertian(env, size), pins[key + "_lambertian"])
+        mips = orc.ggx_mip_levels(w, w, size)
+        assert mips >= 1
+        for m in range(1, mips + 1):
+            np.testing.assert_array_equal(orc.ggx_level(env, w >> m, w >> m, m, mips), pins["%s_ggx%d" % (key, m)])
+            n += 1
+    assert n == 12 and len(pins.files) == 22
 
 
 def test_mt19937_known_answer(orc):
