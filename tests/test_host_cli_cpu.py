@@ -66,3 +66,51 @@ def test_cli_without_work_flags_only_loads(tmp_path):
     r = _run(CUBE, str(src))
     assert r.returncode == 0, r.stderr
     assert sorted(os.listdir(tmp_path)) == ["env.png"]
+
+
+SCENE = """["s72-v1",
+ {"type":"MESH","name":"m","topology":"TRIANGLE_LIST","count":3},
+ {"type":"ENVIRONMENT","name":"sky","radiance":{"src":"env/sky.png","type":"cube","format":"rgbe"}},
+ {"type":"NODE","name":"n \\"quoted\\"","environment":2,"children":[]},
+ {"type":"ENVIRONMENT","name":"room","local":{"minCorner":[0,0,0],"maxCorner":[1,1,1.5e0]}},
+ {"type":"ENVIRONMENT","name":"mirror","local":{"mesh":1,"distance":2.5}}
+]"""
+
+
+def test_scene_mode_lists_environments_like_the_loader(tmp_path):
+    """scene_loader.cpp:113-116,509-535: environments are numbered in order of
+    appearance; a radiance cube is <scene dir>/<src>, a local one
+    <scene>.localIBL_<number>.png."""
+    scene = tmp_path / "demo.s72"
+    scene.write_text(SCENE)
+    (tmp_path / "env").mkdir()
+    (tmp_path / "env" / "sky.png").write_bytes(b"")
+    r = _run(CUBE, "--scene", str(scene), "--list-environments")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == [
+        'Environment 0 "sky": %s' % (tmp_path / "env" / "sky.png"),
+        'Environment 1 "room": %s (local) (missing)' % (tmp_path / "demo.localIBL_1.png"),
+        'Environment 2 "mirror": %s (local) (missing)' % (tmp_path / "demo.localIBL_2.png"),
+    ]
+
+
+@pytest.mark.parametrize("text,message", [
+    ('["s72-v2"]', "first element of scene JSON is not correct magic string"),
+    ('{"a":1}', "scene JSON is not an array"),
+    ('["s72-v1", {"type":"ENVIRONMENT","name":"e","radiance":{"src":"a.png"}}]', "texture has an unexpected type"),
+    ('["s72-v1", {"type":"ENVIRONMENT","name":"e","radiance":{"type":"cube"}}]', "texture does not have a source"),
+    ('["s72-v1", {"type":"ENVIRONMENT"', "Scene loading error: JSON"),
+])
+def test_scene_mode_errors(tmp_path, text, message):
+    scene = tmp_path / "bad.s72"
+    scene.write_text(text)
+    r = _run(CUBE, "--scene", str(scene), "--list-environments")
+    assert r.returncode != 0
+    assert message in r.stderr
+
+
+def test_scene_mode_argument_errors():
+    r = _run(CUBE, "--scene")
+    assert r.returncode != 0 and "missing argument to --scene" in r.stderr
+    r = _run(CUBE, "--scene", "/nonexistent.s72")
+    assert r.returncode != 0 and "cannot open" in r.stderr

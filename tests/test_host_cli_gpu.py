@@ -44,6 +44,36 @@ def test_cube_cli_bake(tmp_path, orc):
         assert byte_identical_fraction(got, want) >= 0.999
 
 
+def test_cube_cli_scene_batch(tmp_path, orc):
+    """--scene bakes what the scene loader will look for (scene_loader.cpp:509-583): the
+    radiance cube of environment 0 and the captured strip of local environment 1; the
+    local environment 2 has no capture yet and is skipped."""
+    (tmp_path / "env").mkdir()
+    sky = vra.synth.hdr_environment(32, seed=5)
+    room = vra.synth.hdr_environment(16, seed=6)
+    write_png(str(tmp_path / "env" / "sky.png"), sky)
+    write_png(str(tmp_path / "demo.localIBL_1.png"), room)
+    (tmp_path / "demo.s72").write_text("""["s72-v1",
+     {"type":"ENVIRONMENT","name":"sky","radiance":{"src":"env/sky.png","type":"cube","format":"rgbe"}},
+     {"type":"ENVIRONMENT","name":"room","local":{"minCorner":[0,0,0],"maxCorner":[1,1,1]}},
+     {"type":"ENVIRONMENT","name":"mirror","local":{"mesh":1,"distance":2.5}}]""")
+    r = subprocess.run([CUBE, "--lambertian", "--ggx", "--cubemap-size", "8", "--scene", str(tmp_path / "demo.s72")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(tmp_path / "env")) == ["sky.ggx1.png", "sky.ggx2.png", "sky.lambertian.png", "sky.png"]
+    assert sorted(os.listdir(tmp_path)) == ["demo.localIBL_1.ggx1.png", "demo.localIBL_1.lambertian.png",
+                                            "demo.localIBL_1.png", "demo.s72", "env"]
+    for strip, stem, w in ((sky, tmp_path / "env" / "sky", 32), (room, tmp_path / "demo.localIBL_1", 16)):
+        env = decode_strip(orc, strip)
+        want = orc.rgbe_encode(orc.lambertian(env, 8)).reshape(6 * 8, 8, 4)
+        assert byte_identical_fraction(read_png(str(stem) + ".lambertian.png"), want) >= 0.999
+        mips = orc.ggx_mip_levels(w, w, 8)
+        for m in range(1, mips + 1):
+            ow = w >> m
+            want = orc.rgbe_encode(orc.ggx_level(env, ow, ow, m, mips)).reshape(6 * ow, ow, 4)
+            assert byte_identical_fraction(read_png("%s.ggx%d.png" % (stem, m)), want) >= 0.999
+
+
 def test_cube_cli_ggx_too_small_input_fails_cleanly(tmp_path):
     strip = vra.synth.hdr_environment(32, seed=1)
     src = tmp_path / "tiny.png"

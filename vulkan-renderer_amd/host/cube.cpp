@@ -4,6 +4,12 @@
 //
 //   cube [--lambertian] [--ggx] [--cubemap-size N] [--input-downscale D] file.png
 //   cube --generate-ggx-lut > ggx_lut.inl
+//   cube [same flags] --scene scene.s72        every environment the scene refers to
+//   cube --scene scene.s72 --list-environments   only print which files those are
+//
+// --scene is an addition: it bakes, in one process, the files the renderer's scene
+// loader will look for (src/scene_loader.cpp:509-583) -- the radiance cube of each
+// ENVIRONMENT object and the captured <scene>.localIBL_<n>.png of each local one.
 //
 // Differences from the reference, all outside the numerics: errors end the
 // process with a message and EXIT_FAILURE instead of an uncaught exception
@@ -12,6 +18,7 @@
 // jitter seed that the reference draws from std::random_device (cube.cpp:342).
 #include "ibl_hip.h"
 #include "png_io.hpp"
+#include "s72_scene.hpp"
 
 #include <charconv>
 #include <cstdlib>
@@ -56,65 +63,36 @@ void generate_ggx_lut() {
     std::cout << "}" << std::endl;
 }
 
-int run(int argc, char** argv) {
-    bool do_lambertian = false, do_ggx = false;
+struct BakeOptions {
+    bool lambertian = false, ggx = false;
     uint32_t cubemap_size = 16, input_downscale = 1;
-    std::optional<std::string> input_file;
+};
 
-    int i = 1;
-    const std::vector<std::string_view> args(argv + 0, argv + argc);
-    while (i < argc) {
-        std::string_view arg = args[i];
-        if (arg == "--lambertian") do_lambertian = true;
-        else if (arg == "--ggx") do_ggx = true;
-        else if (arg == "--cubemap-size") {
-            if (++i >= argc) PANIC("missing argument to --cubemap-size");
-            std::string_view s = args[i];
-            auto r = std::from_chars(s.data(), s.data() + s.size(), cubemap_size);
-            if (r.ec == std::errc::invalid_argument || r.ec == std::errc::result_out_of_range)
-                PANIC("invalid argument to --cubemap-size");
-        } else if (arg == "--input-downscale") {
-            if (++i >= argc) PANIC("missing argument to --input-downscale");
-            std::string_view s = args[i];
-            auto r = std::from_chars(s.data(), s.data() + s.size(), input_downscale);
-            if (r.ec == std::errc::invalid_argument || r.ec == std::errc::result_out_of_range)
-                PANIC("invalid argument to --input-downscale");
-            if (input_downscale == 0 || (input_downscale & (input_downscale - 1)) != 0)
-                PANIC("scale factor for --input-downscale should be a power of 2 >= 1");
-        } else if (arg == "--generate-ggx-lut") {
-            check(ibl_init(-1));
-            generate_ggx_lut();
-            return 0;
-        } else if (!input_file.has_value()) input_file = std::string(arg);
-        else PANIC("invalid command line argument: " + std::string(arg));
-        i++;
-    }
-    if (!input_file.has_value()) PANIC("command line arguments do not have an input file listed");
-    std::filesystem::path input_path = input_file.value();
-
+// The body of the reference's main after argument parsing, cube.cpp:455-516.
+void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) {
     uint32_t w = 0, h = 0;
     std::vector<uint8_t> pixels;
     std::string err;
     if (!png_read_rgba8(input_path.string(), w, h, pixels, err)) PANIC("failed to load texture image! (" + err + ")");
     h /= 6;
     if (w == 0 || h != w) PANIC("input must be a W x 6W strip of square cube faces");
-    if (!do_lambertian && !do_ggx) return 0;
+    if (!opt.lambertian && !opt.ggx) return;
 
     check(ibl_init(-1));
-    const uint32_t mips = do_ggx ? ibl_ggx_mip_levels(w, h, cubemap_size) : 0;
-    std::vector<uint8_t> lambertian(do_lambertian ? (size_t)cubemap_size * cubemap_size * 6 * 4 : 0);
+    const uint32_t mips = opt.ggx ? ibl_ggx_mip_levels(w, h, opt.cubemap_size) : 0;
+    std::vector<uint8_t> lambertian(opt.lambertian ? (size_t)opt.cubemap_size * opt.cubemap_size * 6 * 4 : 0);
     size_t ggx_bytes = 0;
     for (uint32_t m = 1; m <= mips; m++) ggx_bytes += (size_t)(w >> m) * (w >> m) * 6 * 4;
     std::vector<uint8_t> ggx(ggx_bytes);
-    check(ibl_bake_rgbe(pixels.data(), w, input_downscale, cubemap_size,
-                        do_lambertian ? lambertian.data() : nullptr, (do_ggx && mips) ? ggx.data() : nullptr));
+    check(ibl_bake_rgbe(pixels.data(), w, opt.input_downscale, opt.cubemap_size,
+                        opt.lambertian ? lambertian.data() : nullptr, (opt.ggx && mips) ? ggx.data() : nullptr));
 
-    if (do_lambertian) {
+    if (opt.lambertian) {
         std::cout << "Integrating Lambertian: [" << std::flush;
         print_bar();
         std::filesystem::path out = input_path;
         out.replace_extension(".lambertian.png");
-        if (!png_write_rgba8(out.string(), cubemap_size, cubemap_size * 6, lambertian.data(), err)) PANIC(err);
+        if (!png_write_rgba8(out.string(), opt.cubemap_size, opt.cubemap_size * 6, lambertian.data(), err)) PANIC(err);
     }
     size_t off = 0;
     for (uint32_t m = 1; m <= mips; m++) {
@@ -126,6 +104,66 @@ int run(int argc, char** argv) {
         if (!png_write_rgba8(out.string(), mw, mw * 6, ggx.data() + off, err)) PANIC(err);
         off += (size_t)mw * mw * 6 * 4;
     }
+}
+
+// Every environment of a scene, in the loader's numbering.
+void bake_scene(const std::filesystem::path& scene_file, const BakeOptions& opt, bool list_only) {
+    const std::vector<SceneEnvironment> envs = scene_environments(scene_file);
+    for (size_t n = 0; n < envs.size(); n++) {
+        const SceneEnvironment& e = envs[n];
+        std::cout << "Environment " << n << " \"" << e.name << "\": ";
+        if (e.file.empty()) { std::cout << "no radiance or local description" << std::endl; continue; }
+        const bool present = std::filesystem::exists(e.file);
+        std::cout << e.file.string() << (e.local ? " (local)" : "") << (present ? "" : " (missing)") << std::endl;
+        if (list_only || !present) continue;   // the loader also skips environments whose file is absent (:559)
+        bake_file(e.file, opt);
+    }
+}
+
+int run(int argc, char** argv) {
+    BakeOptions opt;
+    std::optional<std::string> input_file, scene_file;
+    bool list_only = false;
+
+    int i = 1;
+    const std::vector<std::string_view> args(argv + 0, argv + argc);
+    while (i < argc) {
+        std::string_view arg = args[i];
+        if (arg == "--lambertian") opt.lambertian = true;
+        else if (arg == "--ggx") opt.ggx = true;
+        else if (arg == "--cubemap-size") {
+            if (++i >= argc) PANIC("missing argument to --cubemap-size");
+            std::string_view s = args[i];
+            auto r = std::from_chars(s.data(), s.data() + s.size(), opt.cubemap_size);
+            if (r.ec == std::errc::invalid_argument || r.ec == std::errc::result_out_of_range)
+                PANIC("invalid argument to --cubemap-size");
+        } else if (arg == "--input-downscale") {
+            if (++i >= argc) PANIC("missing argument to --input-downscale");
+            std::string_view s = args[i];
+            auto r = std::from_chars(s.data(), s.data() + s.size(), opt.input_downscale);
+            if (r.ec == std::errc::invalid_argument || r.ec == std::errc::result_out_of_range)
+                PANIC("invalid argument to --input-downscale");
+            if (opt.input_downscale == 0 || (opt.input_downscale & (opt.input_downscale - 1)) != 0)
+                PANIC("scale factor for --input-downscale should be a power of 2 >= 1");
+        } else if (arg == "--generate-ggx-lut") {
+            check(ibl_init(-1));
+            generate_ggx_lut();
+            return 0;
+        } else if (arg == "--scene") {
+            if (++i >= argc) PANIC("missing argument to --scene");
+            scene_file = std::string(args[i]);
+        } else if (arg == "--list-environments") list_only = true;
+        else if (!input_file.has_value()) input_file = std::string(arg);
+        else PANIC("invalid command line argument: " + std::string(arg));
+        i++;
+    }
+    if (scene_file.has_value()) {
+        if (input_file.has_value()) PANIC("invalid command line argument: " + input_file.value());
+        bake_scene(scene_file.value(), opt, list_only);
+        return 0;
+    }
+    if (!input_file.has_value()) PANIC("command line arguments do not have an input file listed");
+    bake_file(input_file.value(), opt);
     return 0;
 }
 
