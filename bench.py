@@ -53,6 +53,10 @@ def parse_args():
     ap.add_argument("--input-downscale", type=int, default=1,
                     help="c3/c5: box-filter the environment by this power of two first, as the tool's "
                          "--input-downscale does (mip sizes still derive from the full size)")
+    ap.add_argument("--ggx-samples", type=int, default=0,
+                    help="c3/c5: use the sampled GGX mode with this many samples per output texel (an addition; "
+                         "0 = the reference's quadrature, the measured configuration)")
+    ap.add_argument("--ggx-lod-bias", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -105,6 +109,7 @@ class Workload:
                 _, oc = sharding.shard_range(n_out // 8, rank, world)
                 self.levels.append(dict(m=m, ow=ow, n_out=n_out, count=oc * 8,
                                         out=t.zeros((6, ow, ow, 4), dtype=t.float32, device=ibl.device)))
+            self.ggx_samples, self.lod_bias = args.ggx_samples, args.ggx_lod_bias
             # work counts, measured once by the counting kernels outside the timed region
             ibl.set_counting(True)
             tested = accepted = 0
@@ -126,6 +131,18 @@ class Workload:
                          "samples = in-patch texel tests (%.3g tested, %.3g accepted)"
                          % (name[1], self.in_w, self.in_w, self.mips, self.down, tested, accepted))
             self.bytes_per_launch = 32 * 6 * self.env_w * self.env_w + 16 * lv1["count"]
+            if self.ggx_samples:
+                # sampled mode: a sample is one (output texel, half vector) evaluation; ranks take
+                # contiguous ranges of output texels and gather them
+                self.samples = sum(lv["n_out"] for lv in self.levels) * self.ggx_samples
+                for lv in self.levels:
+                    lv["begin"], lv["count"] = sharding.shard_range(lv["n_out"], rank, world)
+                self.flop_per_launch = 150.0 * self.levels[0]["count"] * self.ggx_samples
+                self.kernel = "ggx_sampled_texels (level 1)"
+                self.desc = ("C%s (sampled GGX mode, not the reference's algorithm): chain of a %dx%d/face environment, "
+                             "%d levels, --input-downscale %d, %d samples per output texel, lod bias %g"
+                             % (name[1], self.in_w, self.in_w, self.mips, self.down, self.ggx_samples, self.lod_bias))
+                self.bytes_per_launch = 16 * 6 * self.env_w * self.env_w * 4 // 3 + 16 * self.levels[0]["count"]
             if name == "c5":
                 # plus the Lambertian irradiance of the 1024x1024/face (2x box-filtered) environment,
                 # or of the downscaled one when --input-downscale is coarser than that
@@ -173,6 +190,18 @@ class Workload:
                 ibl.lambertian_shard(self.lam_env, self.lam_w, self.rank, self.world, out=self.lam_out)
                 if self.world > 1:
                     self._all_reduce(self.lam_out)
+            if self.ggx_samples:
+                pyr = ibl.env_pyramid(self.env)
+                for lv in self.levels:
+                    ibl.ggx_level_sampled(pyr, self.env_w, lv["ow"], lv["m"], self.mips, self.ggx_samples, self.lod_bias,
+                                          out_begin=lv["begin"], out_count=lv["count"], out=lv["out"])
+                    if lv["m"] == 1:
+                        self.kernel_ms.append(ibl.last_kernel_ms() if lv["count"] else 0.0)
+                    if self.world > 1:
+                        if self.host_staged_collectives:
+                            ibl.torch.cuda.synchronize()
+                        self.sharding.all_gather_ranges(d, lv["out"].view(-1, 4), lv["n_out"], self.rank, self.world)
+                return
             for lv in self.levels:
                 if self.world > 1:
                     lv["out"].zero_()
@@ -210,6 +239,25 @@ def cpu_baseline(wl, target_seconds):
         want = want.reshape(-1, 4)[begin:begin + count]
         units = count * wl.n_in
         sample = "%d of %d output texels (range %d..%d) x all %d input texels" % (count, n_out, begin, begin + count, wl.n_in)
+    elif wl.name in ("c3", "c5") and wl.ggx_samples:
+        # sampled mode: the CPU statement of the same estimator, same samples
+        lv = wl.levels[1]
+        n_out = lv["n_out"]
+        pyr = oracle.env_pyramid(env)
+        pilot = min(n_out, 32 * ncores)
+        t0 = time.time()
+        oracle.ggx_level_sampled(pyr, wl.env_w, lv["ow"], lv["m"], wl.mips, wl.ggx_samples, wl.lod_bias, n_out // 2, pilot)
+        rate = pilot / max(time.time() - t0, 1e-3)
+        count = int(max(pilot, min(n_out, rate * target_seconds)))
+        begin = (n_out - count) // 2
+        t0 = time.time()
+        want = oracle.ggx_level_sampled(pyr, wl.env_w, lv["ow"], lv["m"], wl.mips, wl.ggx_samples, wl.lod_bias, begin, count)
+        dt = time.time() - t0
+        got = lv["out"].cpu().numpy().reshape(-1, 4)[begin:begin + count]
+        want = want.reshape(-1, 4)[begin:begin + count]
+        units = count * wl.ggx_samples
+        sample = ("sampled mode, level 2 of %d, %d of %d output texels (range %d..%d) x %d samples"
+                  % (wl.mips, count, n_out, begin, begin + count, wl.ggx_samples))
     elif wl.name in ("c3", "c5"):
         lv = wl.levels[1]          # level 2: representative cost, full hemisphere
         n_out = lv["n_out"]
@@ -340,7 +388,7 @@ def main():
         try:   # measured HBM traffic of the same launch, from the committed rocprofv3 PMC passes
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tr = json.load(f).get(wl.name)
-            if tr and world == 1:
+            if tr and world == 1 and not getattr(wl, "ggx_samples", 0):
                 line["roofline"]["traffic"] = tr["bytes"]
                 line["roofline"]["traffic_source"] = tr["source"]
         except OSError:

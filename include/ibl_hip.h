@@ -114,11 +114,40 @@ int ibl_downscale_dev(const float* d_env, uint32_t w, uint32_t h, uint32_t d, fl
  * getNormalFrom vector instead (cube.cpp:103,187). */
 int ibl_texel_directions_dev(uint32_t w, uint32_t h, int normalized, float* d_out, void* stream);
 
+/* ---- sampled GGX mode (no counterpart in the reference) -------------------- */
+
+/* The reference integrates every GGX level over all input texels (cube.cpp:240-313).
+ * This mode estimates the same normalised integral, including the reference's cutoff
+ * window (cube.cpp:284-290), with n_samples GGX-distributed half vectors per output
+ * texel (Hammersley points) and filtered reads from a box pyramid of the environment.
+ * Results approach the quadrature as n_samples grows (lod_bias 0); they are never
+ * byte-identical with it.  For callers that trade accuracy for time (previews, large
+ * environments). */
+
+/* Number of levels and of float4 texels of the box pyramid of a w x w x 6 cube: sizes
+ * w, w/2, ... down to an odd size or 1; level k+1 is the 2x2 box mean of level k (the
+ * filter of cube.cpp:482-501 with factor 2). */
+uint32_t ibl_env_pyramid_levels(uint32_t w);
+uint64_t ibl_env_pyramid_texels(uint32_t w);
+
+/* Fills d_pyramid (ibl_env_pyramid_texels(w) float4, levels back to back, level 0 first). */
+int ibl_env_pyramid_dev(const float* d_env, uint32_t w, float* d_pyramid, void* stream);
+
+/* One level (size out_w, roughness mip_level / mip_levels as in cube.cpp:161-170) for the
+ * output texels [out_begin, out_begin + out_count); lod_bias is added to the pyramid level
+ * chosen for a sample (1.0 is the usual choice for small n_samples). */
+int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t out_w, uint32_t mip_level,
+                              uint32_t mip_levels, uint32_t n_samples, float lod_bias, uint32_t out_begin,
+                              uint32_t out_count, float* d_out, void* stream);
+
 /* ---- host-buffer entry points -------------------------------------------- */
 
 int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* out);
 int ibl_ggx_level(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
                   uint32_t mip_level, uint32_t mip_levels, float* out);
+/* Sampled mode on host buffers: builds the pyramid of env, then the level. */
+int ibl_ggx_level_sampled(const float* env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                          uint32_t n_samples, float lod_bias, float* out);
 int ibl_brdf_lut(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
                  float* out_slope_bias);
 int ibl_rgbe_decode(const uint8_t* rgbe, float* rgba, uint32_t n);
@@ -133,6 +162,11 @@ int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* o
  * (cube.cpp:473-474,513). */
 int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
                   uint8_t* lambertian_out, uint8_t* ggx_out);
+
+/* The same bake with the GGX levels computed by the sampled mode above (ggx_samples > 0;
+ * 0 selects the quadrature, i.e. ibl_bake_rgbe).  No counterpart in the reference. */
+int ibl_bake_rgbe_sampled(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
+                          uint32_t ggx_samples, float lod_bias, uint8_t* lambertian_out, uint8_t* ggx_out);
 
 /* ---- measurement ---------------------------------------------------------- */
 

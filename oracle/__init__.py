@@ -38,6 +38,12 @@ def lib():
         L.orc_normal_from.restype = None
         L.orc_texel_directions.argtypes = [_u32, _u32, ctypes.c_int, _f32p]
         L.orc_texel_directions.restype = None
+        L.orc_pyramid_levels.argtypes = [_u32]
+        L.orc_pyramid_levels.restype = _u32
+        L.orc_pyramid_offset.argtypes = [_u32, _u32]
+        L.orc_pyramid_offset.restype = ctypes.c_uint64
+        L.orc_ggx_level_sampled.argtypes = [_f32p, _u32, _u32, _u32, _u32, _u32, ctypes.c_float, _u32, _u32, _f32p]
+        L.orc_ggx_level_sampled.restype = ctypes.c_int
         L.orc_lambertian.argtypes = [_f32p, _u32, _u32, _u32, _u32, _u32, _f32p, ctypes.c_int]
         L.orc_lambertian.restype = ctypes.c_int
         L.orc_ggx_mip_levels.argtypes = [_u32, _u32, _u32]
@@ -122,6 +128,42 @@ def ggx_level(env, out_w, out_h, mip, mips, out_begin=0, out_count=None, want_co
         raise RuntimeError("orc_ggx_level failed: %d" % rc)
     if want_counts:
         return out, dict(patch_tests=counts[0], tested=counts[1], accepted=counts[2])
+    return out
+
+
+def pyramid_levels(w):
+    return lib().orc_pyramid_levels(w)
+
+
+def pyramid_offset(w, level):
+    """float4 offset of a level inside the packed pyramid."""
+    return lib().orc_pyramid_offset(w, level)
+
+
+def env_pyramid(env):
+    """Box pyramid of a square cube: level k+1 is the 2x2 box mean of level k (the tool's
+    --input-downscale filter applied with factor 2).  -> flat float32 array of float4 texels,
+    levels back to back."""
+    env = _env(env)
+    w = env.shape[2]
+    levels = pyramid_levels(w)
+    parts = [env]
+    for _ in range(1, levels):
+        parts.append(downscale(parts[-1], 2))
+    return np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
+
+
+def ggx_level_sampled(pyramid, in_w, out_w, mip, mips, n_samples, lod_bias=1.0, out_begin=0, out_count=None):
+    """The sampled GGX mode (an extension without a counterpart in the reference)."""
+    n_out = 6 * out_w * out_w
+    if out_count is None:
+        out_count = n_out - out_begin
+    out = np.zeros((6, out_w, out_w, 4), np.float32)
+    pyramid = np.ascontiguousarray(pyramid, dtype=np.float32)
+    rc = lib().orc_ggx_level_sampled(pyramid, in_w, out_w, mip, mips, n_samples, lod_bias, out_begin, out_count,
+                                     out.reshape(-1))
+    if rc:
+        raise RuntimeError("orc_ggx_level_sampled failed: %d" % rc)
     return out
 
 

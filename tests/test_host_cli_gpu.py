@@ -95,3 +95,22 @@ def test_cube_cli_generate_ggx_lut():
     d = vals - ref
     assert abs(d[..., 0].mean()) < 2e-5
     assert np.sqrt((d[128, :, 0] ** 2).mean()) < 1.3e-3 and np.sqrt((d[255, :, 0] ** 2).mean()) < 1.6e-4
+
+
+def test_cube_cli_sampled_ggx(tmp_path, orc):
+    """--ggx-samples (an addition): same files and geometry, GGX levels from the sampled
+    mode; compared with that mode's CPU statement."""
+    strip = vra.synth.hdr_environment(64, seed=11)
+    src = tmp_path / "sky.png"
+    write_png(str(src), strip)
+    r = subprocess.run([CUBE, "--ggx", "--cubemap-size", "16", "--ggx-samples", "256", "--ggx-lod-bias", "0.5", str(src)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(tmp_path)) == ["sky.ggx1.png", "sky.ggx2.png", "sky.png"]
+    env = decode_strip(orc, strip)
+    pyr = orc.env_pyramid(env)
+    for m in (1, 2):
+        ow = 64 >> m
+        got = read_png(str(tmp_path / ("sky.ggx%d.png" % m)))
+        want = orc.rgbe_encode(orc.ggx_level_sampled(pyr, 64, ow, m, 2, 256, 0.5)).reshape(6 * ow, ow, 4)
+        assert byte_identical_fraction(got, want) >= 0.999

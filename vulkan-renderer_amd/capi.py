@@ -42,6 +42,11 @@ _SIGNATURES = {
     "ibl_rgbe_encode_dev": ([_vp, _vp, _u32, _vp], _int),
     "ibl_downscale_dev": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_texel_directions_dev": ([_u32, _u32, _int, _vp, _vp], _int),
+    "ibl_env_pyramid_levels": ([_u32], _u32),
+    "ibl_env_pyramid_texels": ([_u32], _u64),
+    "ibl_env_pyramid_dev": ([_vp, _u32, _vp, _vp], _int),
+    "ibl_ggx_level_sampled_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, ctypes.c_float, _u32, _u32, _vp, _vp], _int),
+    "ibl_ggx_level_sampled": ([_vp, _u32, _u32, _u32, _u32, _u32, ctypes.c_float, _vp], _int),
     "ibl_lambertian": ([_vp, _u32, _u32, _u32, _vp], _int),
     "ibl_ggx_level": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp], _int),
     "ibl_brdf_lut": ([_u32, _u32, _u32, _u64, _int, _vp], _int),
@@ -49,6 +54,7 @@ _SIGNATURES = {
     "ibl_rgbe_encode": ([_vp, _vp, _u32], _int),
     "ibl_downscale": ([_vp, _u32, _u32, _u32, _vp], _int),
     "ibl_bake_rgbe": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_bake_rgbe_sampled": ([_vp, _u32, _u32, _u32, _u32, ctypes.c_float, _vp, _vp], _int),
     "ibl_set_timing": ([_int], _int),
     "ibl_last_kernel_ms": ([ctypes.POINTER(ctypes.c_float)], _int),
     "ibl_set_counting": ([_int], _int),
@@ -219,6 +225,34 @@ class Ibl:
         self._check(self.lib.ibl_downscale_dev(_ptr(env), w, h, d, _ptr(out), self._stream(stream)))
         return out
 
+    # -- sampled GGX mode (an addition; the reference has only the quadrature) ----------
+    def env_pyramid(self, env, stream=None):
+        """Box pyramid of a square cube as one flat (texels, 4) float32 tensor."""
+        w, h = self._env(env)
+        out = self.torch.empty((self.lib.ibl_env_pyramid_texels(w), 4), dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.ibl_env_pyramid_dev(_ptr(env), w, _ptr(out), self._stream(stream)))
+        return out
+
+    def ggx_level_sampled(self, pyramid, in_w, out_w, mip, mips, n_samples, lod_bias=1.0, out_begin=0, out_count=None,
+                          out=None, stream=None):
+        t = self.torch
+        n_out = 6 * out_w * out_w
+        if out_count is None:
+            out_count = n_out - out_begin
+        if out is None:
+            out = t.zeros((6, out_w, out_w, 4), dtype=t.float32, device=self.device)
+        assert pyramid.is_cuda and pyramid.dtype == t.float32 and pyramid.is_contiguous()
+        self._check(self.lib.ibl_ggx_level_sampled_dev(_ptr(pyramid), in_w, out_w, mip, mips, n_samples, float(lod_bias),
+                                                       out_begin, out_count, _ptr(out), self._stream(stream)))
+        return out
+
+    def ggx_level_sampled_host(self, env, out_w, mip, mips, n_samples, lod_bias=1.0):
+        env = self._np_env(env)
+        out = np.zeros((6, out_w, out_w, 4), np.float32)
+        self._check(self.lib.ibl_ggx_level_sampled(env.ctypes.data, env.shape[2], out_w, mip, mips, n_samples,
+                                                   float(lod_bias), out.ctypes.data))
+        return out
+
     def texel_directions(self, w, h=None, normalized=True, stream=None):
         """(6, h, w, 4) float32: the direction of every texel (getNormalFrom, normalised or raw)."""
         h = w if h is None else h
@@ -286,8 +320,10 @@ class Ibl:
         self._check(self.lib.ibl_downscale(env.ctypes.data, env.shape[2], env.shape[1], d, out.ctypes.data))
         return out
 
-    def bake_rgbe(self, rgbe, input_downscale=1, cubemap_size=16, lambertian=True, ggx=True):
-        """rgbe: (6*W, W, 4) uint8 strip.  Returns (lambertian strip or None, [ggx level strips])."""
+    def bake_rgbe(self, rgbe, input_downscale=1, cubemap_size=16, lambertian=True, ggx=True, ggx_samples=0,
+                  lod_bias=1.0):
+        """rgbe: (6*W, W, 4) uint8 strip.  Returns (lambertian strip or None, [ggx level strips]).
+        ggx_samples > 0 selects the sampled GGX mode (an addition), 0 the reference's quadrature."""
         rgbe = np.ascontiguousarray(rgbe, dtype=np.uint8)
         w = rgbe.shape[1]
         assert rgbe.shape == (6 * w, w, 4), rgbe.shape
@@ -296,9 +332,9 @@ class Ibl:
         sizes = [w >> m for m in range(1, mips + 1)]
         total = sum(6 * s * s * 4 for s in sizes)
         gbuf = np.zeros(max(total, 1), np.uint8) if ggx else None
-        self._check(self.lib.ibl_bake_rgbe(rgbe.ctypes.data, w, input_downscale, cubemap_size,
-                                           lam.ctypes.data if lambertian else None,
-                                           gbuf.ctypes.data if ggx else None))
+        self._check(self.lib.ibl_bake_rgbe_sampled(rgbe.ctypes.data, w, input_downscale, cubemap_size, ggx_samples,
+                                                   float(lod_bias), lam.ctypes.data if lambertian else None,
+                                                   gbuf.ctypes.data if ggx else None))
         levels, off = [], 0
         for s in sizes:
             n = 6 * s * s * 4

@@ -432,6 +432,44 @@ int ibl_downscale_dev(const float* d_env, uint32_t w, uint32_t h, uint32_t d, fl
     return IBL_OK;
 }
 
+uint32_t ibl_env_pyramid_levels(uint32_t w) { return w ? ibl::pyramid_levels(w) : 0; }
+
+uint64_t ibl_env_pyramid_texels(uint32_t w) { return w ? ibl::pyramid_offset(w, ibl::pyramid_levels(w)) : 0; }
+
+int ibl_env_pyramid_dev(const float* d_env, uint32_t w, float* d_pyramid, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_env || !d_pyramid) return fail(IBL_EINVAL, "env_pyramid: null pointer");
+    if (int rc = check_cube(w, w, "env_pyramid input")) return rc;
+    if (w > 8192) return fail(IBL_EINVAL, "env_pyramid: face width %u is above 8192", w);
+    HIP_TRY(ibl::pyramid_launch(d_env, w, d_pyramid, pick(stream)));
+    return IBL_OK;
+}
+
+int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t out_w, uint32_t mip_level,
+                              uint32_t mip_levels, uint32_t n_samples, float lod_bias, uint32_t out_begin,
+                              uint32_t out_count, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_pyramid || !d_out) return fail(IBL_EINVAL, "ggx_sampled: null pointer");
+    if (int rc = check_cube(in_w, in_w, "ggx_sampled input")) return rc;
+    if (int rc = check_cube(out_w, out_w, "ggx_sampled output")) return rc;
+    if (in_w > 8192) return fail(IBL_EINVAL, "ggx_sampled: face width %u is above 8192", in_w);
+    if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
+        return fail(IBL_EINVAL, "ggx_sampled: level %u of %u is out of range", mip_level, mip_levels);
+    if (n_samples == 0 || n_samples > (1u << 24))
+        return fail(IBL_EINVAL, "ggx_sampled: %u samples per texel is out of range (1..2^24)", n_samples);
+    if (!(lod_bias > -64.0f && lod_bias < 64.0f)) return fail(IBL_EINVAL, "ggx_sampled: lod bias out of range");
+    if (int rc = check_range(out_begin, out_count, (uint64_t)out_w * out_w * 6, "ggx_sampled")) return rc;
+    g.last_counts[0] = 0;
+    g.last_counts[1] = g.last_counts[2] = (uint64_t)out_count * n_samples;
+    g.counts_pending = false;
+    if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
+    HIP_TRY(ibl::ggx_sampled_launch(d_pyramid, in_w, out_w, mip_level, mip_levels, n_samples, lod_bias, out_begin,
+                                    out_count, d_out, pick(stream), g.timing ? g.ev0 : nullptr,
+                                    g.timing ? g.ev1 : nullptr));
+    g.timed_valid = g.timing;
+    return IBL_OK;
+}
+
 int ibl_texel_directions_dev(uint32_t w, uint32_t h, int normalized, float* d_out, void* stream) {
     if (int rc = check_ready()) return rc;
     if (!d_out) return fail(IBL_EINVAL, "texel_directions: null pointer");
@@ -487,6 +525,22 @@ int ibl_ggx_level(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_w
     return stage_out(out, out_bytes);
 }
 
+int ibl_ggx_level_sampled(const float* env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                          uint32_t n_samples, float lod_bias, float* out) {
+    if (int rc = check_ready()) return rc;
+    if (!env || !out) return fail(IBL_EINVAL, "ggx_sampled: null pointer");
+    if (int rc = check_cube(in_w, in_w, "ggx_sampled input")) return rc;
+    if (int rc = check_cube(out_w, out_w, "ggx_sampled output")) return rc;
+    const size_t in_bytes = (size_t)in_w * in_w * 6 * 16, out_bytes = (size_t)out_w * out_w * 6 * 16;
+    if (int rc = stage_in(env, in_bytes)) return rc;
+    if (int rc = ensure(g.a, (size_t)ibl_env_pyramid_texels(in_w) * 16)) return rc;
+    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
+    if (int rc = ibl_env_pyramid_dev((const float*)g.stage_in.ptr, in_w, (float*)g.a.ptr, nullptr)) return rc;
+    if (int rc = ibl_ggx_level_sampled_dev((const float*)g.a.ptr, in_w, out_w, mip_level, mip_levels, n_samples, lod_bias,
+                                           0, out_w * out_w * 6, (float*)g.stage_out.ptr, nullptr)) return rc;
+    return stage_out(out, out_bytes);
+}
+
 int ibl_brdf_lut(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
                  float* out_slope_bias) {
     if (int rc = check_ready()) return rc;
@@ -534,6 +588,11 @@ int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* o
 
 int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
                   uint8_t* lambertian_out, uint8_t* ggx_out) {
+    return ibl_bake_rgbe_sampled(rgbe_in, w, input_downscale, cubemap_size, 0, 0.0f, lambertian_out, ggx_out);
+}
+
+int ibl_bake_rgbe_sampled(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
+                          uint32_t ggx_samples, float lod_bias, uint8_t* lambertian_out, uint8_t* ggx_out) {
     if (int rc = check_ready()) return rc;
     if (!rgbe_in) return fail(IBL_EINVAL, "bake: null input");
     if (int rc = check_cube(w, w, "bake input")) return rc;
@@ -575,11 +634,18 @@ int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, 
         HIP_TRY(hipMemcpyAsync(lambertian_out, d_e, (size_t)n_lamb * 4, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
     }
+    if (mips && ggx_samples) {      // sampled mode: one pyramid of the (downscaled) environment for all levels
+        if (int rc = ensure(g.b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
+        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)g.b.ptr, nullptr)) return rc;
+    }
     size_t out_off = 0;
     uint32_t mw = w / 2;
     for (uint32_t m = 1; m <= mips; m++, mw /= 2) {
         const uint32_t n_m = mw * mw * 6;
-        if (int rc = ibl_ggx_level_dev(d_env, dw, dw, mw, mw, m, mips, 0, n_m, d_f, nullptr)) return rc;
+        if (ggx_samples) {
+            if (int rc = ibl_ggx_level_sampled_dev((const float*)g.b.ptr, dw, mw, m, mips, ggx_samples, lod_bias, 0, n_m,
+                                                   d_f, nullptr)) return rc;
+        } else if (int rc = ibl_ggx_level_dev(d_env, dw, dw, mw, mw, m, mips, 0, n_m, d_f, nullptr)) return rc;
         if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n_m, nullptr)) return rc;
         HIP_TRY(hipMemcpyAsync(ggx_out + out_off, d_e, (size_t)n_m * 4, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));

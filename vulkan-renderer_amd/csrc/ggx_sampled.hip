@@ -1,0 +1,205 @@
+// Sampled GGX prefilter (one mip level) for gfx950 -- an addition without a counterpart
+// in the reference, whose integrateGGX (src/utilities/cube.cpp:152-309) visits every
+// input texel.  This mode estimates the same normalised integral
+//     sum L D(NoH) NoH NoL cw^2 / sum D(NoH) NoH NoL cw^2
+// (NoL dw: cube.cpp:274-276; D NoH: :279-281; cutoff window cw: :284-290) with N half
+// vectors drawn from D(h) NoH around n = v on Hammersley points, so a sample weighs
+// NoH NoL cw^2, and reads the environment through a box pyramid at the level whose
+// texel matches the sample's solid angle (1 / (N pdf)), trilinearly, with taps that
+// leave a face taken from the neighbouring face.
+//
+// env_pyramid_levels   level k+1 = 2x2 box mean of level k (the tool's downscale filter).
+// ggx_sampled_texels   one wavefront per output texel; lane j takes samples j, j+64, ...;
+//     FP32 sums per lane, fixed-shape FP64 butterfly, so a texel's value depends on
+//     (level, texel, N, bias) only.  The gathers are the work: 8 taps per sample.
+#include "ibl_device.h"
+#include "ibl_kernels.h"
+#include <math.h>
+
+namespace ibl {
+
+uint32_t pyramid_levels(uint32_t w) {
+    uint32_t n = 1;
+    while (w > 1 && (w & 1u) == 0) { w >>= 1; n++; }
+    return n;
+}
+
+uint64_t pyramid_offset(uint32_t w, uint32_t level) {
+    uint64_t off = 0;
+    for (uint32_t k = 0; k < level; k++) off += (uint64_t)6 * (w >> k) * (w >> k);
+    return off;
+}
+
+hipError_t pyramid_launch(const float* d_env, uint32_t w, float* d_pyramid, hipStream_t stream) {
+    const uint32_t levels = pyramid_levels(w);
+    hipError_t e = hipMemcpyAsync(d_pyramid, d_env, (size_t)6 * w * w * 16, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
+    for (uint32_t k = 1; k < levels; k++) {
+        const uint32_t pw = w >> (k - 1);
+        e = downscale_launch(d_pyramid + 4 * pyramid_offset(w, k - 1), pw, pw, 2, d_pyramid + 4 * pyramid_offset(w, k), stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+struct Pyramid {
+    const float4* base;
+    uint32_t w, levels;
+    uint32_t off[16];   // float4 offset of each level (a 2^15 face has 16 levels; offsets fit 32 bits up to 8192)
+};
+
+// Table of getNormalFrom (cube.cpp:35-46) for fractional (s, t).
+__device__ __forceinline__ F3 face_dir(uint32_t face, float s, float t) {
+    F3 r;
+    switch (face) {
+        case 0: r.x = 1.0f;  r.y = -t;    r.z = -s;   break;
+        case 1: r.x = -1.0f; r.y = -t;    r.z = s;    break;
+        case 2: r.x = s;     r.y = 1.0f;  r.z = t;    break;
+        case 3: r.x = s;     r.y = -1.0f; r.z = -t;   break;
+        case 4: r.x = s;     r.y = -t;    r.z = 1.0f; break;
+        default: r.x = -s;   r.y = -t;    r.z = -1.0f; break;
+    }
+    return r;
+}
+
+// Its inverse: direction -> (face, s, t).
+__device__ __forceinline__ void dir_to_face(F3 d, uint32_t& face, float& s, float& t) {
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    if (ax >= ay && ax >= az) {
+        const float inv = 1.0f / ax;
+        if (d.x > 0.0f) { face = 0; s = -d.z * inv; t = -d.y * inv; }
+        else            { face = 1; s = d.z * inv;  t = -d.y * inv; }
+    } else if (ay >= az) {
+        const float inv = 1.0f / ay;
+        if (d.y > 0.0f) { face = 2; s = d.x * inv; t = d.z * inv; }
+        else            { face = 3; s = d.x * inv; t = -d.z * inv; }
+    } else {
+        const float inv = 1.0f / az;
+        if (d.z > 0.0f) { face = 4; s = d.x * inv;  t = -d.y * inv; }
+        else            { face = 5; s = -d.x * inv; t = -d.y * inv; }
+    }
+}
+
+__device__ __forceinline__ float4 pyr_texel(const Pyramid& p, uint32_t level, uint32_t face, int x, int y) {
+    const int S = (int)(p.w >> level);
+    if (x < 0 || y < 0 || x >= S || y >= S) {
+        const float s = ((float)x + 0.5f) / (float)S * 2.0f - 1.0f;
+        const float t = ((float)y + 0.5f) / (float)S * 2.0f - 1.0f;
+        const F3 d = face_dir(face, s, t);
+        float s2, t2;
+        dir_to_face(d, face, s2, t2);
+        x = (int)floorf((s2 + 1.0f) * 0.5f * (float)S);
+        y = (int)floorf((t2 + 1.0f) * 0.5f * (float)S);
+        x = x < 0 ? 0 : (x >= S ? S - 1 : x);
+        y = y < 0 ? 0 : (y >= S ? S - 1 : y);
+    }
+    return p.base[p.off[level] + (face * (uint32_t)S + (uint32_t)y) * (uint32_t)S + (uint32_t)x];
+}
+
+__device__ __forceinline__ F3 pyr_bilinear(const Pyramid& p, uint32_t level, F3 dir) {
+#pragma clang fp contract(off)
+    uint32_t face; float s, t;
+    dir_to_face(dir, face, s, t);
+    const float S = (float)(p.w >> level);
+    const float fx = (s + 1.0f) * 0.5f * S - 0.5f, fy = (t + 1.0f) * 0.5f * S - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float4 c00 = pyr_texel(p, level, face, x0, y0), c10 = pyr_texel(p, level, face, x0 + 1, y0);
+    const float4 c01 = pyr_texel(p, level, face, x0, y0 + 1), c11 = pyr_texel(p, level, face, x0 + 1, y0 + 1);
+    F3 r;
+    { float a = c00.x + wx * (c10.x - c00.x), b = c01.x + wx * (c11.x - c01.x); r.x = a + wy * (b - a); }
+    { float a = c00.y + wx * (c10.y - c00.y), b = c01.y + wx * (c11.y - c01.y); r.y = a + wy * (b - a); }
+    { float a = c00.z + wx * (c10.z - c00.z), b = c01.z + wx * (c11.z - c01.z); r.z = a + wy * (b - a); }
+    return r;
+}
+
+__device__ __forceinline__ F3 pyr_sample(const Pyramid& p, F3 dir, float lod) {
+#pragma clang fp contract(off)
+    const float top = (float)(p.levels - 1);
+    lod = lod < 0.0f ? 0.0f : (lod > top ? top : lod);
+    const float l0f = floorf(lod);
+    const uint32_t l0 = (uint32_t)l0f;
+    const float f = lod - l0f;
+    F3 a = pyr_bilinear(p, l0, dir);
+    if (f > 0.0f) {
+        const F3 b = pyr_bilinear(p, l0 + 1, dir);
+        a.x = a.x + f * (b.x - a.x); a.y = a.y + f * (b.y - a.y); a.z = a.z + f * (b.z - a.z);
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void ggx_sampled_texels(Pyramid p, uint32_t out_w, float a2, float cutoff,
+                                                           uint32_t n_samples, float lod_bias, uint32_t out_begin,
+                                                           uint32_t out_count, float4* __restrict__ out) {
+#pragma clang fp contract(off)
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t local = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (local >= out_count) return;              // whole wave leaves: no barrier below
+    const uint32_t o = out_begin + local;
+    const F3 n = ref_out_normal(o, out_w, out_w);
+    const F3 up = fabsf(n.z) < 0.999f ? F3{0.0f, 0.0f, 1.0f} : F3{1.0f, 0.0f, 0.0f};
+    const F3 tx = ref_normalize(F3{up.y * n.z - up.z * n.y, up.z * n.x - up.x * n.z, up.x * n.y - up.y * n.x});
+    const F3 bx = { n.y * tx.z - n.z * tx.y, n.z * tx.x - n.x * tx.z, n.x * tx.y - n.y * tx.x };
+    const float inv_n = 1.0f / (float)n_samples;
+    const float texel_scale = 4.0f / ((float)p.w * (float)p.w);
+    const float pi = 3.14159265358979323846f;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
+    double dx = 0.0, dy = 0.0, dz = 0.0, dw = 0.0;
+    uint32_t pending = 0;
+    for (uint32_t i = lane; i < n_samples; i += 64) {
+        const float u1 = ((float)i + 0.5f) * inv_n;
+        const float u2 = (float)__brev(i) * 2.3283064365386963e-10f;
+        const float cos2 = (1.0f - u2) / (1.0f + (a2 - 1.0f) * u2);
+        const float nol = 2.0f * cos2 - 1.0f;
+        if (!(nol > 0.0f) || !(cos2 > cutoff)) continue;
+        const float cw = (cos2 - cutoff) / (1.0f - cutoff);
+        const float cos_t = sqrtf(cos2), sin_t = sqrtf(1.0f - cos2);
+        const float w = nol * cos_t * (cw * cw);
+        const float phi = 2.0f * pi * u1;
+        const float cx = sin_t * cosf(phi), cy = sin_t * sinf(phi);
+        const F3 h = { cx * tx.x + cy * bx.x + cos_t * n.x, cx * tx.y + cy * bx.y + cos_t * n.y,
+                       cx * tx.z + cy * bx.z + cos_t * n.z };
+        const float k2 = 2.0f * cos_t;
+        const F3 l = { k2 * h.x - n.x, k2 * h.y - n.y, k2 * h.z - n.z };
+        const float d = cos2 * (a2 - 1.0f) + 1.0f;
+        const float pdf = a2 / (pi * d * d) * 0.25f;
+        const float m = fmaxf(fabsf(l.x), fmaxf(fabsf(l.y), fabsf(l.z)));
+        const float omega_s = inv_n / pdf;
+        const float omega_p = texel_scale * m * m * m;
+        const float lod = 0.5f * log2f(omega_s / omega_p) + lod_bias;
+        const F3 c = pyr_sample(p, l, lod);
+        ax += w * c.x; ay += w * c.y; az += w * c.z; aw += w;
+        if (++pending == 64) {     // FP32 sums cover 64 samples, then go to FP64
+            dx += (double)ax; dy += (double)ay; dz += (double)az; dw += (double)aw;
+            ax = ay = az = aw = 0.0f; pending = 0;
+        }
+    }
+    dx += (double)ax; dy += (double)ay; dz += (double)az; dw += (double)aw;
+    for (int off = 32; off > 0; off >>= 1) {
+        dx += __shfl_xor(dx, off); dy += __shfl_xor(dy, off); dz += __shfl_xor(dz, off); dw += __shfl_xor(dw, off);
+    }
+    if (lane == 0) {
+        const double inv = 1.0 / dw;
+        out[o] = make_float4((float)(inv * dx), (float)(inv * dy), (float)(inv * dz), 0.0f);
+    }
+}
+
+hipError_t ggx_sampled_launch(const float* d_pyramid, uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips,
+                              uint32_t n_samples, float lod_bias, uint32_t out_begin, uint32_t out_count, float* d_out,
+                              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const GgxLevel lv = ggx_level_params(mip, mips, in_w, in_w);
+    Pyramid p;
+    p.base = (const float4*)d_pyramid;
+    p.w = in_w;
+    p.levels = pyramid_levels(in_w);
+    for (uint32_t k = 0; k < 16; k++) p.off[k] = k < p.levels ? (uint32_t)pyramid_offset(in_w, k) : 0u;
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    if (out_count)
+        ggx_sampled_texels<<<(out_count + 3) / 4, 256, 0, stream>>>(p, out_w, lv.alpha2, lv.cutoff, n_samples, lod_bias,
+                                                                    out_begin, out_count, (float4*)d_out);
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    return hipGetLastError();
+}
+
+}  // namespace ibl

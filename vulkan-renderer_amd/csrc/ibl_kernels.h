@@ -90,6 +90,14 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
                           float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
                           hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
+// Sampled GGX mode (ggx_sampled.hip): box pyramid of the environment and the level kernel.
+uint32_t pyramid_levels(uint32_t w);
+uint64_t pyramid_offset(uint32_t w, uint32_t level);     // in float4 texels
+hipError_t pyramid_launch(const float* d_env, uint32_t w, float* d_pyramid, hipStream_t stream);
+hipError_t ggx_sampled_launch(const float* d_pyramid, uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips,
+                              uint32_t n_samples, float lod_bias, uint32_t out_begin, uint32_t out_count, float* d_out,
+                              hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+
 hipError_t brdf_lut_launch(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int mode,
                            uint32_t cell_begin, uint32_t cell_count, float* d_out, hipStream_t stream,
                            hipEvent_t ev0, hipEvent_t ev1);

@@ -4,6 +4,9 @@
 //
 //   cube [--lambertian] [--ggx] [--cubemap-size N] [--input-downscale D] file.png
 //   cube --generate-ggx-lut > ggx_lut.inl
+//   cube [same flags] --ggx-samples N [--ggx-lod-bias B] file.png
+//                                             GGX levels by N importance samples per texel
+//                                             (an addition; the default is the reference's quadrature)
 //   cube [same flags] --scene scene.s72        every environment the scene refers to
 //   cube --scene scene.s72 --list-environments   only print which files those are
 //
@@ -66,6 +69,8 @@ void generate_ggx_lut() {
 struct BakeOptions {
     bool lambertian = false, ggx = false;
     uint32_t cubemap_size = 16, input_downscale = 1;
+    uint32_t ggx_samples = 0;      // 0: quadrature over all input texels, as the reference
+    float ggx_lod_bias = 1.0f;
 };
 
 // The body of the reference's main after argument parsing, cube.cpp:455-516.
@@ -84,8 +89,8 @@ void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) 
     size_t ggx_bytes = 0;
     for (uint32_t m = 1; m <= mips; m++) ggx_bytes += (size_t)(w >> m) * (w >> m) * 6 * 4;
     std::vector<uint8_t> ggx(ggx_bytes);
-    check(ibl_bake_rgbe(pixels.data(), w, opt.input_downscale, opt.cubemap_size,
-                        opt.lambertian ? lambertian.data() : nullptr, (opt.ggx && mips) ? ggx.data() : nullptr));
+    check(ibl_bake_rgbe_sampled(pixels.data(), w, opt.input_downscale, opt.cubemap_size, opt.ggx_samples, opt.ggx_lod_bias,
+                                opt.lambertian ? lambertian.data() : nullptr, (opt.ggx && mips) ? ggx.data() : nullptr));
 
     if (opt.lambertian) {
         std::cout << "Integrating Lambertian: [" << std::flush;
@@ -145,6 +150,18 @@ int run(int argc, char** argv) {
                 PANIC("invalid argument to --input-downscale");
             if (opt.input_downscale == 0 || (opt.input_downscale & (opt.input_downscale - 1)) != 0)
                 PANIC("scale factor for --input-downscale should be a power of 2 >= 1");
+        } else if (arg == "--ggx-samples") {
+            if (++i >= argc) PANIC("missing argument to --ggx-samples");
+            std::string_view s = args[i];
+            auto r = std::from_chars(s.data(), s.data() + s.size(), opt.ggx_samples);
+            if (r.ec == std::errc::invalid_argument || r.ec == std::errc::result_out_of_range || opt.ggx_samples == 0)
+                PANIC("invalid argument to --ggx-samples");
+        } else if (arg == "--ggx-lod-bias") {
+            if (++i >= argc) PANIC("missing argument to --ggx-lod-bias");
+            char* end = nullptr;
+            const std::string s(args[i]);
+            opt.ggx_lod_bias = std::strtof(s.c_str(), &end);
+            if (end == s.c_str() || *end != '\0') PANIC("invalid argument to --ggx-lod-bias");
         } else if (arg == "--generate-ggx-lut") {
             check(ibl_init(-1));
             generate_ggx_lut();
