@@ -9,7 +9,7 @@ from helpers import decode_strip
 
 pytestmark = pytest.mark.gpu
 
-STATEMENT_TOL = 2e-5     # GPU vs CPU statement: only libm/ocml rounding differs (measured <= 5e-6)
+STATEMENT_TOL = 1e-4     # GPU vs CPU statement: libm vs the 1-ulp hardware sin/cos/log2/rcp/sqrt (measured <= 3e-5)
 
 
 def _dev(ibl, arr):

@@ -48,6 +48,11 @@ struct Pyramid {
     uint32_t off[16];   // float4 offset of each level (a 2^15 face has 16 levels; offsets fit 32 bits up to 8192)
 };
 
+// Per-sample arithmetic uses the 1-ulp hardware reciprocal, square root, logarithm and
+// sine/cosine (the latter take revolutions, which is what the Hammersley coordinate is):
+// a sample's direction and level move by ~1e-7, far below what the filtered lookup resolves.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // Table of getNormalFrom (cube.cpp:35-46) for fractional (s, t).
 __device__ __forceinline__ F3 face_dir(uint32_t face, float s, float t) {
     F3 r;
@@ -62,32 +67,38 @@ __device__ __forceinline__ F3 face_dir(uint32_t face, float s, float t) {
     return r;
 }
 
-// Its inverse: direction -> (face, s, t).
+// Its inverse: direction -> (face, s, t).  EXACT selects correctly rounded division: the
+// rare taps that leave a face are snapped to a texel of the neighbouring face, and at small
+// odd face sizes their direction can sit exactly on a texel boundary there, so that path
+// repeats the CPU statement's arithmetic to the bit.
+template <bool EXACT>
 __device__ __forceinline__ void dir_to_face(F3 d, uint32_t& face, float& s, float& t) {
+#pragma clang fp contract(off)
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     if (ax >= ay && ax >= az) {
-        const float inv = 1.0f / ax;
+        const float inv = EXACT ? ref_div(1.0f, ax) : fast_rcp(ax);
         if (d.x > 0.0f) { face = 0; s = -d.z * inv; t = -d.y * inv; }
         else            { face = 1; s = d.z * inv;  t = -d.y * inv; }
     } else if (ay >= az) {
-        const float inv = 1.0f / ay;
+        const float inv = EXACT ? ref_div(1.0f, ay) : fast_rcp(ay);
         if (d.y > 0.0f) { face = 2; s = d.x * inv; t = d.z * inv; }
         else            { face = 3; s = d.x * inv; t = -d.z * inv; }
     } else {
-        const float inv = 1.0f / az;
+        const float inv = EXACT ? ref_div(1.0f, az) : fast_rcp(az);
         if (d.z > 0.0f) { face = 4; s = d.x * inv;  t = -d.y * inv; }
         else            { face = 5; s = -d.x * inv; t = -d.y * inv; }
     }
 }
 
 __device__ __forceinline__ float4 pyr_texel(const Pyramid& p, uint32_t level, uint32_t face, int x, int y) {
+#pragma clang fp contract(off)
     const int S = (int)(p.w >> level);
     if (x < 0 || y < 0 || x >= S || y >= S) {
-        const float s = ((float)x + 0.5f) / (float)S * 2.0f - 1.0f;
-        const float t = ((float)y + 0.5f) / (float)S * 2.0f - 1.0f;
+        const float s = ref_div((float)x + 0.5f, (float)S) * 2.0f - 1.0f;
+        const float t = ref_div((float)y + 0.5f, (float)S) * 2.0f - 1.0f;
         const F3 d = face_dir(face, s, t);
         float s2, t2;
-        dir_to_face(d, face, s2, t2);
+        dir_to_face<true>(d, face, s2, t2);
         x = (int)floorf((s2 + 1.0f) * 0.5f * (float)S);
         y = (int)floorf((t2 + 1.0f) * 0.5f * (float)S);
         x = x < 0 ? 0 : (x >= S ? S - 1 : x);
@@ -99,7 +110,7 @@ __device__ __forceinline__ float4 pyr_texel(const Pyramid& p, uint32_t level, ui
 __device__ __forceinline__ F3 pyr_bilinear(const Pyramid& p, uint32_t level, F3 dir) {
 #pragma clang fp contract(off)
     uint32_t face; float s, t;
-    dir_to_face(dir, face, s, t);
+    dir_to_face<false>(dir, face, s, t);
     const float S = (float)(p.w >> level);
     const float fx = (s + 1.0f) * 0.5f * S - 0.5f, fy = (t + 1.0f) * 0.5f * S - 0.5f;
     const float x0f = floorf(fx), y0f = floorf(fy);
@@ -142,32 +153,32 @@ __global__ __launch_bounds__(256) void ggx_sampled_texels(Pyramid p, uint32_t ou
     const F3 tx = ref_normalize(F3{up.y * n.z - up.z * n.y, up.z * n.x - up.x * n.z, up.x * n.y - up.y * n.x});
     const F3 bx = { n.y * tx.z - n.z * tx.y, n.z * tx.x - n.x * tx.z, n.x * tx.y - n.y * tx.x };
     const float inv_n = 1.0f / (float)n_samples;
-    const float texel_scale = 4.0f / ((float)p.w * (float)p.w);
     const float pi = 3.14159265358979323846f;
+    const float inv_window = 1.0f / (1.0f - cutoff);
+    const float lod_scale = inv_n * (4.0f * pi / a2) / (4.0f / ((float)p.w * (float)p.w));
     float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
     double dx = 0.0, dy = 0.0, dz = 0.0, dw = 0.0;
     uint32_t pending = 0;
     for (uint32_t i = lane; i < n_samples; i += 64) {
         const float u1 = ((float)i + 0.5f) * inv_n;
         const float u2 = (float)__brev(i) * 2.3283064365386963e-10f;
-        const float cos2 = (1.0f - u2) / (1.0f + (a2 - 1.0f) * u2);
+        const float cos2 = (1.0f - u2) * fast_rcp(1.0f + (a2 - 1.0f) * u2);
         const float nol = 2.0f * cos2 - 1.0f;
         if (!(nol > 0.0f) || !(cos2 > cutoff)) continue;
-        const float cw = (cos2 - cutoff) / (1.0f - cutoff);
-        const float cos_t = sqrtf(cos2), sin_t = sqrtf(1.0f - cos2);
+        const float cw = (cos2 - cutoff) * inv_window;
+        const float cos_t = __builtin_amdgcn_sqrtf(cos2), sin_t = __builtin_amdgcn_sqrtf(1.0f - cos2);
         const float w = nol * cos_t * (cw * cw);
-        const float phi = 2.0f * pi * u1;
-        const float cx = sin_t * cosf(phi), cy = sin_t * sinf(phi);
+        const float cx = sin_t * __builtin_amdgcn_cosf(u1), cy = sin_t * __builtin_amdgcn_sinf(u1);   // cos, sin of 2 pi u1
         const F3 h = { cx * tx.x + cy * bx.x + cos_t * n.x, cx * tx.y + cy * bx.y + cos_t * n.y,
                        cx * tx.z + cy * bx.z + cos_t * n.z };
         const float k2 = 2.0f * cos_t;
         const F3 l = { k2 * h.x - n.x, k2 * h.y - n.y, k2 * h.z - n.z };
         const float d = cos2 * (a2 - 1.0f) + 1.0f;
-        const float pdf = a2 / (pi * d * d) * 0.25f;
+        // solid angle of the sample over solid angle of a level-0 texel in that direction:
+        // (1 / (N pdf)) / (4 m^3 / W^2), pdf = D / 4, D = a2 / (pi d^2)
         const float m = fmaxf(fabsf(l.x), fmaxf(fabsf(l.y), fabsf(l.z)));
-        const float omega_s = inv_n / pdf;
-        const float omega_p = texel_scale * m * m * m;
-        const float lod = 0.5f * log2f(omega_s / omega_p) + lod_bias;
+        const float ratio = (d * d) * lod_scale * fast_rcp(m * m * m);
+        const float lod = 0.5f * __builtin_amdgcn_logf(ratio) + lod_bias;
         const F3 c = pyr_sample(p, l, lod);
         ax += w * c.x; ay += w * c.y; az += w * c.z; aw += w;
         if (++pending == 64) {     // FP32 sums cover 64 samples, then go to FP64
