@@ -126,7 +126,10 @@ int ibl_texel_directions_dev(uint32_t w, uint32_t h, int normalized, float* d_ou
 
 /* Number of levels and of float4 texels of the box pyramid of a w x w x 6 cube: sizes
  * w, w/2, ... down to an odd size or 1; level k+1 is the 2x2 box mean of level k (the
- * filter of cube.cpp:482-501 with factor 2). */
+ * filter of cube.cpp:482-501 with factor 2).  Every face of every level is stored with
+ * a one-texel apron ((S+2) x (S+2) texels for an S x S face) that holds, for each tap
+ * position just outside the face, the texel of the neighbouring face its direction
+ * falls on; the layout is the library's own, fill it with ibl_env_pyramid_dev. */
 uint32_t ibl_env_pyramid_levels(uint32_t w);
 uint64_t ibl_env_pyramid_texels(uint32_t w);
 

@@ -42,6 +42,10 @@ def lib():
         L.orc_pyramid_levels.restype = _u32
         L.orc_pyramid_offset.argtypes = [_u32, _u32]
         L.orc_pyramid_offset.restype = ctypes.c_uint64
+        L.orc_pyramid_padded_offset.argtypes = [_u32, _u32]
+        L.orc_pyramid_padded_offset.restype = ctypes.c_uint64
+        L.orc_pyramid_pad.argtypes = [_f32p, _u32, _f32p]
+        L.orc_pyramid_pad.restype = None
         L.orc_ggx_level_sampled.argtypes = [_f32p, _u32, _u32, _u32, _u32, _u32, ctypes.c_float, _u32, _u32, _f32p]
         L.orc_ggx_level_sampled.restype = ctypes.c_int
         L.orc_lambertian.argtypes = [_f32p, _u32, _u32, _u32, _u32, _u32, _f32p, ctypes.c_int]
@@ -151,6 +155,16 @@ def env_pyramid(env):
     for _ in range(1, levels):
         parts.append(downscale(parts[-1], 2))
     return np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
+
+
+def env_pyramid_padded(env):
+    """The pyramid in the layout of the GPU library: one-texel apron around every face."""
+    env = _env(env)
+    w = env.shape[2]
+    flat = env_pyramid(env)
+    out = np.zeros(4 * lib().orc_pyramid_padded_offset(w, pyramid_levels(w)), np.float32)
+    lib().orc_pyramid_pad(flat, w, out)
+    return out
 
 
 def ggx_level_sampled(pyramid, in_w, out_w, mip, mips, n_samples, lod_bias=1.0, out_begin=0, out_count=None):

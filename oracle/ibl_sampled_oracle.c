@@ -111,6 +111,33 @@ static void s_texel(const pyramid_t* p, uint32_t level, int face, int x, int y, 
     out[0] = q[0]; out[1] = q[1]; out[2] = q[2];
 }
 
+/* The layout the GPU library keeps the pyramid in: every face of every level with a
+ * one-texel apron, apron position (x, y) (x or y equal to -1 or S) holding the texel that
+ * s_texel returns for it.  Offsets in float4 texels. */
+uint64_t orc_pyramid_padded_offset(uint32_t w, uint32_t level) {
+    uint64_t off = 0;
+    for (uint32_t k = 0; k < level; k++) off += (uint64_t)6 * ((w >> k) + 2) * ((w >> k) + 2);
+    return off;
+}
+
+void orc_pyramid_pad(const float* pyramid, uint32_t w, float* out) {
+    pyramid_t p = { pyramid, w, orc_pyramid_levels(w) };
+    for (uint32_t level = 0; level < p.levels; level++) {
+        const int S = (int)(w >> level), P = S + 2;
+        float* dst = out + 4 * orc_pyramid_padded_offset(w, level);
+        for (int face = 0; face < 6; face++)
+            for (int y = -1; y <= S; y++)
+                for (int x = -1; x <= S; x++) {
+                    float c[3];
+                    s_texel(&p, level, face, x, y, c);
+                    float* q = dst + 4 * (((size_t)face * P + (y + 1)) * P + (x + 1));
+                    q[0] = c[0]; q[1] = c[1]; q[2] = c[2];
+                    /* alpha: 1 from the decoder at level 0, 0 from the box filter above it */
+                    q[3] = level == 0 ? 1.0f : 0.0f;
+                }
+    }
+}
+
 static void s_bilinear(const pyramid_t* p, uint32_t level, s3f dir, float out[3]) {
     int face; float s, t;
     s_dir_to_face(dir, &face, &s, &t);

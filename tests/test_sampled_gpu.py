@@ -20,7 +20,7 @@ def _dev(ibl, arr):
 def test_env_pyramid_bit_exact(ibl, orc, w):
     env = decode_strip(orc, vra.synth.hdr_environment(w, seed=w))
     got = ibl.env_pyramid(_dev(ibl, env)).cpu().numpy().reshape(-1)
-    want = orc.env_pyramid(env)
+    want = orc.env_pyramid_padded(env)       # the library keeps a one-texel apron around every face
     assert ibl.lib.ibl_env_pyramid_levels(w) == orc.pyramid_levels(w)
     assert got.size == want.size == 4 * ibl.lib.ibl_env_pyramid_texels(w)
     assert (got.view(np.uint32) == want.view(np.uint32)).all()

@@ -20,16 +20,18 @@
 //   ggx_oct_prep / ggx_oct_prep_patches   per level: one 7-float4 record per input texel
 //       octet (canonical unit direction, |w|^-3, radiance*|w|^-3 of the 8 members), stored
 //       patch-octet-major; canonical unit centre direction per patch octet.
-//   ggx_oct_pairs   grid = (blocks of 256 output octets in tile-major order) x (interleaved
-//       slices of patch octets); every wave of 64 octets works alone.  Per 64 patch octets a
+//   ggx_oct_pairs   grid = (units of 64 output octets in tile-major order) x (interleaved
+//       slices of patch octets), one wave per workgroup; every wave works alone, and a
+//       level is cut into at least 131072 of them.  Per 64 patch octets a
 //       bounding-cone test marks, per lane, the candidate (patch octet, sign patterns); the
 //       wave visits the candidates in patch order (ballot + readlane); every lane runs the
 //       reference's exact float patch test for its own octet and each candidate pattern; the
 //       wave walks the patch's records once, reading them with wave-uniform (scalar) loads,
 //       and evaluates the patterns that pass for any of its lanes.  FP32 sums cover 64
 //       records, then go to FP64 running sums.  No LDS, no barriers.
-//   ggx_oct_final   per output octet: slices summed in order in FP64, divided, scattered
-//       to the member texels that lie in the requested (face, y, x) range.
+//   ggx_oct_reduce / ggx_oct_final   per output octet: slices summed in a fixed two-stage
+//       order in FP64, divided, scattered to the member texels that lie in the requested
+//       (face, y, x) range.
 // A texel's value does not depend on the range or shard a call covers.
 #include "ibl_device.h"
 #include "ibl_kernels.h"

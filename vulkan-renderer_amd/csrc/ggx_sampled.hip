@@ -8,7 +8,10 @@
 // texel matches the sample's solid angle (1 / (N pdf)), trilinearly, with taps that
 // leave a face taken from the neighbouring face.
 //
-// env_pyramid_levels   level k+1 = 2x2 box mean of level k (the tool's downscale filter).
+// pyramid_level0 / pyramid_next   level k+1 = 2x2 box mean of level k (the tool's downscale
+//     filter); every face of every level is stored with a one-texel apron that holds, for
+//     each tap position just outside the face, the texel of the neighbouring face its
+//     direction falls on -- so the sampling loop never leaves a face's own array.
 // ggx_sampled_texels   one wavefront per output texel; lane j takes samples j, j+64, ...;
 //     FP32 sums per lane, fixed-shape FP64 butterfly, so a texel's value depends on
 //     (level, texel, N, bias) only.  The gathers are the work: 8 taps per sample.
@@ -26,26 +29,14 @@ uint32_t pyramid_levels(uint32_t w) {
 
 uint64_t pyramid_offset(uint32_t w, uint32_t level) {
     uint64_t off = 0;
-    for (uint32_t k = 0; k < level; k++) off += (uint64_t)6 * (w >> k) * (w >> k);
+    for (uint32_t k = 0; k < level; k++) off += (uint64_t)6 * ((w >> k) + 2) * ((w >> k) + 2);
     return off;
-}
-
-hipError_t pyramid_launch(const float* d_env, uint32_t w, float* d_pyramid, hipStream_t stream) {
-    const uint32_t levels = pyramid_levels(w);
-    hipError_t e = hipMemcpyAsync(d_pyramid, d_env, (size_t)6 * w * w * 16, hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) return e;
-    for (uint32_t k = 1; k < levels; k++) {
-        const uint32_t pw = w >> (k - 1);
-        e = downscale_launch(d_pyramid + 4 * pyramid_offset(w, k - 1), pw, pw, 2, d_pyramid + 4 * pyramid_offset(w, k), stream);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
 }
 
 struct Pyramid {
     const float4* base;
     uint32_t w, levels;
-    uint32_t off[16];   // float4 offset of each level (a 2^15 face has 16 levels; offsets fit 32 bits up to 8192)
+    uint32_t off[16];   // float4 offset of each (padded) level; offsets fit 32 bits up to 8192-texel faces
 };
 
 // Per-sample arithmetic uses the 1-ulp hardware reciprocal, square root, logarithm and
@@ -90,21 +81,76 @@ __device__ __forceinline__ void dir_to_face(F3 d, uint32_t& face, float& s, floa
     }
 }
 
-__device__ __forceinline__ float4 pyr_texel(const Pyramid& p, uint32_t level, uint32_t face, int x, int y) {
+// The texel a tap at (x, y) just outside face `face` of an S-texel level stands for: the
+// one of the neighbouring face that the tap's direction falls on.  Correctly rounded
+// arithmetic, the same as the CPU statement's: at small odd S such a direction can sit
+// exactly on a texel boundary.
+__device__ __forceinline__ void snap_tap(uint32_t& face, int& x, int& y, int S) {
 #pragma clang fp contract(off)
-    const int S = (int)(p.w >> level);
-    if (x < 0 || y < 0 || x >= S || y >= S) {
-        const float s = ref_div((float)x + 0.5f, (float)S) * 2.0f - 1.0f;
-        const float t = ref_div((float)y + 0.5f, (float)S) * 2.0f - 1.0f;
-        const F3 d = face_dir(face, s, t);
-        float s2, t2;
-        dir_to_face<true>(d, face, s2, t2);
-        x = (int)floorf((s2 + 1.0f) * 0.5f * (float)S);
-        y = (int)floorf((t2 + 1.0f) * 0.5f * (float)S);
-        x = x < 0 ? 0 : (x >= S ? S - 1 : x);
-        y = y < 0 ? 0 : (y >= S ? S - 1 : y);
+    const float s = ref_div((float)x + 0.5f, (float)S) * 2.0f - 1.0f;
+    const float t = ref_div((float)y + 0.5f, (float)S) * 2.0f - 1.0f;
+    const F3 d = face_dir(face, s, t);
+    float s2, t2;
+    dir_to_face<true>(d, face, s2, t2);
+    x = (int)floorf((s2 + 1.0f) * 0.5f * (float)S);
+    y = (int)floorf((t2 + 1.0f) * 0.5f * (float)S);
+    x = x < 0 ? 0 : (x >= S ? S - 1 : x);
+    y = y < 0 ? 0 : (y >= S ? S - 1 : y);
+}
+
+// One thread per padded texel (x, y in [-1, S]) of level 0: copy, or the apron rule.
+__global__ __launch_bounds__(256) void pyramid_level0(const float4* __restrict__ env, uint32_t S, float4* __restrict__ out) {
+    const uint32_t P = S + 2, n = 6 * P * P;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t face = k / (P * P);
+    const uint32_t rem = k - face * (P * P);
+    int y = (int)(rem / P) - 1, x = (int)(rem % P) - 1;
+    if (x < 0 || y < 0 || x >= (int)S || y >= (int)S) snap_tap(face, x, y, (int)S);
+    out[k] = env[(face * S + (uint32_t)y) * S + (uint32_t)x];
+}
+
+// One thread per padded texel of the next level: the 2x2 box mean of the previous level's
+// texels (sums in (row, column) order, times 1/4: downscale_box with factor 2) for the texel
+// itself or for the texel its apron position stands for.
+__global__ __launch_bounds__(256) void pyramid_next(const float4* __restrict__ prev, uint32_t S, float4* __restrict__ out) {
+#pragma clang fp contract(off)
+    const uint32_t P = S + 2, n = 6 * P * P;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t face = k / (P * P);
+    const uint32_t rem = k - face * (P * P);
+    int y = (int)(rem / P) - 1, x = (int)(rem % P) - 1;
+    if (x < 0 || y < 0 || x >= (int)S || y >= (int)S) snap_tap(face, x, y, (int)S);
+    const uint32_t PP = 2 * S + 2;                       // padded edge of the previous level
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for (uint32_t yy = 0; yy < 2; yy++)
+        for (uint32_t xx = 0; xx < 2; xx++) {
+            const float4 t = prev[(face * PP + (2 * (uint32_t)y + yy + 1)) * PP + (2 * (uint32_t)x + xx + 1)];
+            ax += t.x; ay += t.y; az += t.z;
+        }
+    const float inv = ref_div(1.0f, 4.0f);
+    out[k] = make_float4(inv * ax, inv * ay, inv * az, 0.0f);
+}
+
+hipError_t pyramid_launch(const float* d_env, uint32_t w, float* d_pyramid, hipStream_t stream) {
+    const uint32_t levels = pyramid_levels(w);
+    float4* base = (float4*)d_pyramid;
+    {
+        const uint32_t n = 6 * (w + 2) * (w + 2);
+        pyramid_level0<<<(n + 255) / 256, 256, 0, stream>>>((const float4*)d_env, w, base);
     }
-    return p.base[p.off[level] + (face * (uint32_t)S + (uint32_t)y) * (uint32_t)S + (uint32_t)x];
+    for (uint32_t k = 1; k < levels; k++) {
+        const uint32_t S = w >> k, n = 6 * (S + 2) * (S + 2);
+        pyramid_next<<<(n + 255) / 256, 256, 0, stream>>>(base + pyramid_offset(w, k - 1), S, base + pyramid_offset(w, k));
+    }
+    return hipGetLastError();
+}
+
+// Texel (x, y), x and y in [-1, S], of a padded level.
+__device__ __forceinline__ float4 pyr_texel(const Pyramid& p, uint32_t level, uint32_t face, int x, int y) {
+    const uint32_t P = (p.w >> level) + 2;
+    return p.base[p.off[level] + (face * P + (uint32_t)(y + 1)) * P + (uint32_t)(x + 1)];
 }
 
 __device__ __forceinline__ F3 pyr_bilinear(const Pyramid& p, uint32_t level, F3 dir) {
@@ -115,7 +161,9 @@ __device__ __forceinline__ F3 pyr_bilinear(const Pyramid& p, uint32_t level, F3 
     const float fx = (s + 1.0f) * 0.5f * S - 0.5f, fy = (t + 1.0f) * 0.5f * S - 0.5f;
     const float x0f = floorf(fx), y0f = floorf(fy);
     const float wx = fx - x0f, wy = fy - y0f;
-    const int x0 = (int)x0f, y0 = (int)y0f;
+    // fx lies in [-0.5, S - 0.5], so the taps are x0, x0 + 1 in [-1, S]; the clamp only guards rounding
+    const int smax = (int)S - 1;
+    const int x0 = min(max((int)x0f, -1), smax), y0 = min(max((int)y0f, -1), smax);
     const float4 c00 = pyr_texel(p, level, face, x0, y0), c10 = pyr_texel(p, level, face, x0 + 1, y0);
     const float4 c01 = pyr_texel(p, level, face, x0, y0 + 1), c11 = pyr_texel(p, level, face, x0 + 1, y0 + 1);
     F3 r;
