@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c1|c2]
 
 A "step" is one pass of the hot path over one synthetic environment that is
-already resident in HBM.  The default workload is BASELINE config 4, the one
+already resident in HBM.  The default workload is configuration 4 of the task's list, the one
 the metric ("env-prefilter GSamples/s at 1/2/4/8 MI355X") is quoted on across
 1-8 GPUs: the brute-force Lambertian convolution of a 1024x1024/face environment
 into 128x128/face (6.18e11 (output, input) texel pairs).  With N > 1 (one process

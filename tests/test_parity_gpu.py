@@ -1,7 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle
 on the same seeded inputs.
 
-Bars (BASELINE.json north_star): decoded radiance within 1e-3 relative per texel,
+Bars: decoded radiance within 1e-3 relative per texel,
 >= 99.9 % of RGBE-encoded texels byte-identical, BRDF table within 1e-4 absolute;
 integer/byte work (RGBE codec, box filter) bit-exact.
 """
@@ -168,7 +168,7 @@ def test_lambertian_parity(ibl, orc, w, out, kernel_mode):
 
 
 def test_lambertian_config1_host_api(ibl, orc):
-    """BASELINE config 1 (64x64/face -> 32x32/face) through the host-buffer entry point."""
+    """The CPU-runnable benchmark configuration (64x64/face -> 32x32/face) through the host-buffer entry point."""
     env, _ = _env(ibl, orc, 64)
     got = ibl.lambertian_host(env, 32)
     _check_cube(orc, got, orc.lambertian(env, 32))
@@ -189,7 +189,7 @@ def test_lambertian_special_environments(ibl, orc, kind, kernel_mode):
 
 
 def test_lambertian_large_input_subset(ibl, orc, kernel_mode):
-    """1024x1024/face input (BASELINE config 4's input), 256 of its 128x128/face
+    """1024x1024/face input (the headline Lambertian configuration's input), 256 of its 128x128/face
     output texels against the oracle; the full output is covered by
     test_lambertian_full_size_properties."""
     env, env_d = _env(ibl, orc, 1024, seed=11)
@@ -204,7 +204,7 @@ def test_lambertian_large_input_subset(ibl, orc, kernel_mode):
 
 
 def test_lambertian_full_size_properties(ibl, orc, kernel_mode):
-    """BASELINE config 4 at full size through size-independent properties:
+    """The headline Lambertian configuration (1024x1024/face -> 128x128/face) at full size through size-independent properties:
     a sharded bake equals the unsharded one bit for bit, a constant environment
     comes back as (quadrature-exact) that constant, and the operator is linear."""
     env, env_d = _env(ibl, orc, 1024, seed=11)
@@ -274,7 +274,7 @@ def test_ggx_counts_match_oracle(ibl, orc, kernel_mode):
 
 
 def test_ggx_512_subset_16x16_patches(ibl, orc, kernel_mode):
-    """BASELINE config 3's input (512x512/face, 16x16 patches): a band of output
+    """The 512x512/face GGX benchmark input (16x16 patches): a band of output
     texels of every level against the oracle."""
     env, env_d = _env(ibl, orc, 512, seed=5)
     mips = orc.ggx_mip_levels(512, 512, 16)
@@ -291,7 +291,7 @@ def test_ggx_512_subset_16x16_patches(ibl, orc, kernel_mode):
 
 
 def test_ggx_2048_subset(ibl, orc):
-    """BASELINE config 5's input (2048x2048/face, 7 levels): 96 output texels of four
+    """The full-bake input (2048x2048/face, 7 levels): 96 output texels of four
     levels against the oracle (the 25M-texel environment makes more too slow on CPU)."""
     env, env_d = _env(ibl, orc, 2048, seed=9)
     mips = orc.ggx_mip_levels(2048, 2048, 16)
