@@ -8,12 +8,17 @@
 // So 3 multiplies, 2 adds and 6 clamped adds give all 64 dot products of an
 // (output octet, input octet) pair (the pattern t = (-,-,-) is never positive),
 // and what remains is the 56 x 3 colour FMAs: 180 VALU instructions per 64 texel
-// pairs instead of 384.  The reference computes each of those 64 products with the
+// pairs instead of 384.  Of the six remaining non-trivial patterns, opposite ones
+// cancel: per lane exactly three are positive, and a wave of neighbouring octets
+// mostly agrees on which, so usually 32 x 3 FMAs are issued, not 56 x 3.  The reference computes each of those 64 products with the
 // same operands in the same order, so sharing them changes nothing it could see.
 //
 // Kernel plan
 //   lambertian_oct_prep    one thread per input octet: canonical g and the 8
-//                          members' radiance packed as 7 float4 (112 B).
+//                          members' radiance, channel-major (R[8], G[8], B[8]), packed
+//                          as 7 float4 (112 B): a packed FMA then reads two neighbouring
+//                          members of one channel, swapped by op_sel where the pattern
+//                          flips x.
 //   lambertian_oct_pairs   grid = (blocks of 256 output octets) x (input slices);
 //                          a thread owns one output octet: 24 FP32 sums over one
 //                          LDS tile of 64 input octets, then FP64 running sums.
@@ -23,6 +28,7 @@
 // A texel's value does not depend on the range or shard a call covers.
 #include "ibl_device.h"
 #include "ibl_kernels.h"
+#include <type_traits>
 
 namespace ibl {
 
@@ -60,12 +66,32 @@ __global__ __launch_bounds__(256) void lambertian_oct_prep(const float4* __restr
     for (uint32_t s = 0; s < 8; s++) {
         Texel t = octet_member(axis, j, i, s, w, h);
         float4 L = env[(t.face * h + t.y) * h + t.x];     // cube.cpp:104 row stride
-        v[3 + 3 * s] = L.x; v[4 + 3 * s] = L.y; v[5 + 3 * s] = L.z;
+        v[4 + s] = L.x; v[12 + s] = L.y; v[20 + s] = L.z;      // channel-major: R[8], G[8], B[8]
     }
-    v[27] = 0.0f;
+    v[3] = 0.0f;
 #pragma unroll
     for (int q = 0; q < OCT_REC; q++)
         rec[(size_t)k * OCT_REC + q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// Output octets are numbered tile-major (tiles of tw x tw canonical positions, tw <= 8), so
+// that the 64 octets of a wave are neighbours on the cube: what a wave can skip below
+// depends on how far apart its directions are.
+__host__ __device__ inline uint32_t oct_tile_edge(uint32_t hw) {
+    uint32_t tw = hw < 8 ? hw : 8;
+    while (hw % tw) tw--;
+    return tw;
+}
+
+__device__ __forceinline__ void oct_decode(uint32_t g, uint32_t hw, uint32_t tw, uint32_t& axis, uint32_t& oj, uint32_t& oi) {
+    const uint32_t t2 = tw * tw, tpr = hw / tw;
+    const uint32_t tile = g / t2, within = g - tile * t2;
+    const uint32_t ly = within / tw, lx = within - ly * tw;
+    axis = tile / (tpr * tpr);
+    const uint32_t trem = tile - axis * (tpr * tpr);
+    const uint32_t ty = trem / tpr, tx = trem - ty * tpr;
+    oj = ty * tw + ly;
+    oi = tx * tw + lx;
 }
 
 // Bit mask of the members of output octet (axis, j, i) whose (face, y, x) index
@@ -100,21 +126,21 @@ __global__ __launch_bounds__(OCT_THREADS, OCT_MIN_WAVES) void lambertian_oct_pai
     const uint32_t lo = blockIdx.x * OCT_THREADS + tid;              // local output octet
     const uint32_t hw = out_size / 2;
     const uint32_t oo = oct_begin + min(lo, oct_count - 1);
-    const uint32_t axis = oo / (hw * hw);
-    const uint32_t rem = oo - axis * (hw * hw);
-    const uint32_t oj = rem / hw, oi = rem - oj * hw;
+    uint32_t axis, oj, oi;
+    oct_decode(oo, hw, oct_tile_edge(hw), axis, oj, oi);
     uint32_t mask = lo < oct_count ? octet_range_mask(axis, oj, oi, out_size, out_begin, out_count) : 0u;
     if (!__syncthreads_or(mask != 0u)) return;
 
     Texel c = octet_member(axis, oj, oi, 0, out_size, out_size);
     const F3 n = ref_normalize(ref_normal_from(c.face, c.x, c.y, out_size, out_size));   // cube.cpp:97
 
-    float acc[8][3];
-    double dacc[8][3];
+    float acc[3][8];        // [channel][member]: neighbours in a pair read neighbours of the record
+    double dacc[3][8];
 #pragma unroll
-    for (int s = 0; s < 8; s++)
+    for (int k = 0; k < 3; k++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) { acc[s][k] = 0.0f; dacc[s][k] = 0.0; }
+        for (int s = 0; s < 8; s++) { acc[k][s] = 0.0f; dacc[k][s] = 0.0; }
+    const unsigned long long full = __ballot(true);     // the wave's live lanes
 
     // Tile staging: OCT_TILE*OCT_REC = 448 float4 per tile, two per thread.
     auto fetch = [&](uint32_t tile, float4& v0, float4& v1) {
@@ -142,29 +168,41 @@ __global__ __launch_bounds__(OCT_THREADS, OCT_MIN_WAVES) void lambertian_oct_pai
             }
             const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
             const float s1 = a + b, s2 = a - b;
-            float t[7];
-            t[0] = s1 + cc;                  // (+,+,+)
-            t[1] = sub_clamp01(cc, s2);      // (-,+,+): -a+b+c
-            t[2] = add_clamp01(s2, cc);      // (+,-,+):  a-b+c
-            t[3] = sub_clamp01(cc, s1);      // (-,-,+): -a-b+c
-            t[4] = sub_clamp01(s1, cc);      // (+,+,-):  a+b-c
-            t[5] = neg_sub_clamp01(s2, cc);  // (-,+,-): -a+b-c
-            t[6] = sub_clamp01(s2, cc);      // (+,-,-):  a-b-c
+            // one sign pattern: output member so pairs with input member so ^ TAU
+            auto accumulate = [&](auto tau_c, float t) {
+                constexpr int TAU = decltype(tau_c)::value;
 #pragma unroll
-            for (int so = 0; so < 8; so++) {
+                for (int k = 0; k < 3; k++)
 #pragma unroll
-                for (int si = 0; si < 8; si++) {
-                    const int tau = so ^ si;
-                    if (tau == 7) continue;  // (-,-,-): never positive
-#pragma unroll
-                    for (int k = 0; k < 3; k++) acc[so][k] = fmaf(t[tau], r[3 + 3 * si + k], acc[so][k]);
-                }
+                    for (int so = 0; so < 8; so++) acc[k][so] = fmaf(t, r[4 + 8 * k + (so ^ TAU)], acc[k][so]);
+            };
+            accumulate(std::integral_constant<int, 0>{}, s1 + cc);      // (+,+,+): always positive
+            // The other six patterns come in three pairs of opposite sign, (t, 7 - t): per lane
+            // exactly one of a pair is positive (cube.cpp:115 drops the other).  When the whole
+            // wave agrees on which, the other one's 24 FMAs are skipped; (-,-,-) never counts.
+            {
+                const float v = cc - s2;                                 // (-,+,+) = -a+b+c; (+,-,-) is -v
+                const unsigned long long pos = __ballot(v > 0.0f);
+                if (pos != 0ull) accumulate(std::integral_constant<int, 1>{}, sub_clamp01(cc, s2));
+                if (pos != full) accumulate(std::integral_constant<int, 6>{}, sub_clamp01(s2, cc));
+            }
+            {
+                const float v = s2 + cc;                                 // (+,-,+) = a-b+c; (-,+,-) is -v
+                const unsigned long long pos = __ballot(v > 0.0f);
+                if (pos != 0ull) accumulate(std::integral_constant<int, 2>{}, add_clamp01(s2, cc));
+                if (pos != full) accumulate(std::integral_constant<int, 5>{}, neg_sub_clamp01(s2, cc));
+            }
+            {
+                const float v = s1 - cc;                                 // (+,+,-) = a+b-c; (-,-,+) is -v
+                const unsigned long long pos = __ballot(v > 0.0f);
+                if (pos != 0ull) accumulate(std::integral_constant<int, 4>{}, sub_clamp01(s1, cc));
+                if (pos != full) accumulate(std::integral_constant<int, 3>{}, sub_clamp01(cc, s1));
             }
         }
 #pragma unroll
-        for (int s = 0; s < 8; s++)
+        for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int k = 0; k < 3; k++) { dacc[s][k] += (double)acc[s][k]; acc[s][k] = 0.0f; }
+            for (int s = 0; s < 8; s++) { dacc[k][s] += (double)acc[k][s]; acc[k][s] = 0.0f; }
         if (tile + 1 < n_tiles) {
             s_rec[cur ^ 1][tid] = v0;
             if (tid + OCT_THREADS < OCT_TILE * OCT_REC) s_rec[cur ^ 1][tid + OCT_THREADS] = v1;
@@ -177,7 +215,7 @@ __global__ __launch_bounds__(OCT_THREADS, OCT_MIN_WAVES) void lambertian_oct_pai
         for (int s = 0; s < 8; s++)
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                partial[((size_t)slice * 24 + (s * 3 + k)) * oct_count + lo] = dacc[s][k];
+                partial[((size_t)slice * 24 + (s * 3 + k)) * oct_count + lo] = dacc[k][s];
     }
 }
 
@@ -191,9 +229,8 @@ __global__ __launch_bounds__(256) void lambertian_oct_final(const double* __rest
     if (lo >= oct_count) return;
     const uint32_t hw = out_size / 2;
     const uint32_t oo = oct_begin + lo;
-    const uint32_t axis = oo / (hw * hw);
-    const uint32_t rem = oo - axis * (hw * hw);
-    const uint32_t oj = rem / hw, oi = rem - oj * hw;
+    uint32_t axis, oj, oi;
+    oct_decode(oo, hw, oct_tile_edge(hw), axis, oj, oi);
     Texel t = octet_member(axis, oj, oi, s, out_size, out_size);
     const uint32_t o = (t.face * out_size + t.y) * out_size + t.x;
     if (o - out_begin >= out_count) return;
