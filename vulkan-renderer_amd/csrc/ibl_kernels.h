@@ -29,8 +29,9 @@ struct LambertianOctPlan {
     uint32_t n_oct_in;     // 3 * (in_w/2)^2
     uint32_t slice_len;    // input octets per slice
     uint32_t n_slices;
+    uint32_t reduce_groups; // > 1: the slices are summed in this many groups first
     uint32_t out_blocks;
-    size_t partial_bytes;  // [slice][24][oct_count] double
+    size_t partial_bytes;  // [slice (+ group)][24][oct_count] double
     size_t rec_bytes;      // 7 float4 per input octet
 };
 LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_size, uint32_t oct_count);

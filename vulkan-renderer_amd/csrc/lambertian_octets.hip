@@ -22,12 +22,14 @@
 //   lambertian_oct_pairs   grid = (blocks of 256 output octets) x (input slices);
 //                          a thread owns one output octet: 24 FP32 sums over one
 //                          LDS tile of 64 input octets, then FP64 running sums.
-//   lambertian_oct_final   per output octet: slices summed in order in FP64,
+//   lambertian_oct_reduce / lambertian_oct_final
+//                          per output octet: slices summed in a fixed two-stage order in FP64,
 //                          scaled, scattered to the 8 member texels that lie in the
 //                          requested (face, y, x) range.
 // A texel's value does not depend on the range or shard a call covers.
 #include "ibl_device.h"
 #include "ibl_kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace ibl {
@@ -109,7 +111,7 @@ __device__ __forceinline__ uint32_t octet_range_mask(uint32_t axis, uint32_t j, 
 }
 
 #ifndef OCT_MIN_WAVES
-#define OCT_MIN_WAVES 3   // measured: 3 is 1 % faster than 1-2, 4-6 are 9-18 % slower
+#define OCT_MIN_WAVES 4   // measured: 4 is 3-4 % faster than 2-3, 5-6 are 10 % slower
 #endif
 __global__ __launch_bounds__(OCT_THREADS, OCT_MIN_WAVES) void lambertian_oct_pairs(
     const float4* __restrict__ rec, uint32_t n_oct_in, uint32_t slice_len,
@@ -219,6 +221,24 @@ __global__ __launch_bounds__(OCT_THREADS, OCT_MIN_WAVES) void lambertian_oct_pai
     }
 }
 
+// First stage of the slice sum: group g adds its run of consecutive slices, in order, into
+// one more set of partial sums.  One thread per (output octet, member, group).
+__global__ __launch_bounds__(256) void lambertian_oct_reduce(const double* __restrict__ partial, uint32_t n_slices,
+                                                              uint32_t per_group, uint32_t oct_count,
+                                                              double* __restrict__ reduced) {
+    const uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.y, g = blockIdx.z;
+    if (lo >= oct_count) return;
+    const uint32_t s0 = g * per_group, s1 = min(n_slices, s0 + per_group);
+    double v[3] = {0.0, 0.0, 0.0};
+    for (uint32_t sl = s0; sl < s1; sl++) {
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) v[k] += partial[((size_t)sl * 24 + (s * 3 + k)) * oct_count + lo];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) reduced[((size_t)g * 24 + (s * 3 + k)) * oct_count + lo] = v[k];
+}
+
 // One thread per (output octet, member): coalesced over the octet index.
 __global__ __launch_bounds__(256) void lambertian_oct_final(const double* __restrict__ partial, uint32_t n_slices,
                                                              uint32_t out_size, uint32_t oct_begin, uint32_t oct_count,
@@ -249,12 +269,19 @@ LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_size, uint32_t
     pl.n_oct_in = 3 * (in_w / 2) * (in_w / 2);
     // Slice length depends on the input size only (range/shard independence).
     uint32_t tiles = (pl.n_oct_in + OCT_TILE - 1) / OCT_TILE;
-    uint32_t tiles_per_slice = (tiles + 127) / 128;          // at most 128 slices
+    // At most 512 slices: an eighth of the output blocks of the largest case (one of 8 GPUs)
+    // then still fills a GPU three times over, and one GPU is 5 % faster than with 128.
+    uint32_t max_slices = 512;
+    if (const char* e = getenv("IBL_LAMB_OCT_SLICES")) max_slices = (uint32_t)atoi(e);   // tuning knob
+    if (max_slices < 1) max_slices = 1;
+    uint32_t tiles_per_slice = (tiles + max_slices - 1) / max_slices;
     if (tiles_per_slice < 2) tiles_per_slice = 2;
     pl.slice_len = tiles_per_slice * OCT_TILE;
     pl.n_slices = (pl.n_oct_in + pl.slice_len - 1) / pl.slice_len;
     pl.out_blocks = (oct_count + OCT_THREADS - 1) / OCT_THREADS;
-    pl.partial_bytes = (size_t)pl.n_slices * 24 * oct_count * sizeof(double);
+    // many slices are summed in two stages (fixed grouping, so still one summation order)
+    pl.reduce_groups = pl.n_slices > 32 ? (pl.n_slices + 31) / 32 : 1;
+    pl.partial_bytes = (size_t)(pl.n_slices + (pl.reduce_groups > 1 ? pl.reduce_groups : 0)) * 24 * oct_count * sizeof(double);
     pl.rec_bytes = (size_t)pl.n_oct_in * OCT_REC * sizeof(float4);
     (void)out_size;
     return pl;
@@ -272,7 +299,17 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
                                                            oct_begin, oct_count, out_begin, out_count, d_partial);
     if (ev1) (void)hipEventRecord(ev1, stream);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);
-    lambertian_oct_final<<<dim3((oct_count + 255) / 256, 8), 256, 0, stream>>>(d_partial, pl.n_slices, out_size, oct_begin,
+    const double* d_sums = d_partial;
+    uint32_t n_sums = pl.n_slices;
+    if (pl.reduce_groups > 1) {
+        double* d_reduced = d_partial + (size_t)pl.n_slices * 24 * oct_count;
+        const uint32_t per_group = (pl.n_slices + pl.reduce_groups - 1) / pl.reduce_groups;
+        lambertian_oct_reduce<<<dim3((oct_count + 255) / 256, 8, pl.reduce_groups), 256, 0, stream>>>(
+            d_partial, pl.n_slices, per_group, oct_count, d_reduced);
+        d_sums = d_reduced;
+        n_sums = pl.reduce_groups;
+    }
+    lambertian_oct_final<<<dim3((oct_count + 255) / 256, 8), 256, 0, stream>>>(d_sums, n_sums, out_size, oct_begin,
                                                                       oct_count, out_begin, out_count, scale,
                                                                       (float4*)d_out);
     return hipGetLastError();
