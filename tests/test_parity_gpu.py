@@ -236,7 +236,7 @@ def test_lambertian_full_size_properties(ibl, orc, kernel_mode):
 
 # ---- GGX ---------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("w,min_size", [(16, 8), (64, 16), (64, 4), (128, 16), (48, 12), (96, 20)])
+@pytest.mark.parametrize("w,min_size", [(16, 8), (64, 16), (64, 4), (128, 16), (48, 12), (96, 20), (100, 16), (40, 10)])
 def test_ggx_chain_parity(ibl, orc, w, min_size, kernel_mode):
     env, env_d = _env(ibl, orc, w)
     mips = orc.ggx_mip_levels(w, w, min_size)

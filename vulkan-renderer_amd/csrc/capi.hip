@@ -284,8 +284,9 @@ int ggx_check(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, 
     if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
         return fail(IBL_EINVAL, "ggx: level %u of %u is out of range", mip_level, mip_levels);
     ibl::GgxLevel lv = ibl::ggx_level_params(mip_level, mip_levels, in_w, in_h);
-    if (in_w % lv.patch != 0)
-        return fail(IBL_EINVAL, "ggx: input width %u is not a multiple of its patch size %u", in_w, lv.patch);
+    // in_w need not be a multiple of the patch size: like the reference (cube.cpp:175-201,
+    // 251-264), the general kernel then leaves the last in_w % patch columns and rows of a
+    // face out of the quadrature.
     *patch = lv.patch;
     return IBL_OK;
 }
