@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void ggx_prep_patches(uint32_t pw, uint32_t ph
 template <int PX, int PY, bool COUNT, bool CORE>
 __global__ __launch_bounds__(GGX_THREADS, 2) void ggx_pairs(
     const float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ pn,
-    uint32_t n_patches, uint32_t patches_per_slice, uint32_t ps2,
+    uint32_t n_patches, uint32_t ps2,
     uint32_t out_w, uint32_t out_h, uint32_t tiles_x, uint32_t tiles_y,
     uint32_t out_begin, uint32_t out_count,
     float cutoff, float a2m1, float cmin, float theta_acc, float core_thr,
@@ -205,7 +205,6 @@ __global__ __launch_bounds__(GGX_THREADS, 2) void ggx_pairs(
     // workgroups of one output tile carry equal shares of its cone.
     const uint32_t n_slices = gridDim.y;
     const uint32_t my_count = (n_patches + n_slices - 1 - blockIdx.y) / n_slices;
-    (void)patches_per_slice;
 
     for (uint32_t base = 0; base < my_count; base += GGX_THREADS) {
         // ---- candidate list of this chunk, in patch order --------------------
@@ -366,7 +365,6 @@ GgxPlan ggx_plan(uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h, u
     uint32_t max_slices = (pl.n_patches + 3) / 4;               // >= 4 patches per slice
     if (max_slices == 0) max_slices = 1;
     uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
-    pl.patches_per_slice = (pl.n_patches + slices - 1) / slices;
     pl.n_slices = slices;
     pl.partial_bytes = (size_t)pl.n_slices * out_count * 4 * sizeof(double);
     const size_t n_in = (size_t)pl.n_patches * ps * ps;
@@ -382,7 +380,7 @@ static void ggx_dispatch(const GgxPlan& pl, dim3 grid, hipStream_t stream, const
                          uint32_t out_count, float a2m1, float cmin, float theta_acc, float core_thr, double* partial,
                          unsigned long long* counts) {
     auto go = [&](auto kernel) {
-        kernel<<<grid, GGX_THREADS, 0, stream>>>(a, b, pn, pl.n_patches, pl.patches_per_slice, ps2, out_w, out_h,
+        kernel<<<grid, GGX_THREADS, 0, stream>>>(a, b, pn, pl.n_patches, ps2, out_w, out_h,
             pl.tiles_x, pl.tiles_y, out_begin, out_count, pl.lv.cutoff, a2m1, cmin, theta_acc, core_thr, partial, counts);
     };
     const bool core = core_thr > 0.0f;

@@ -474,7 +474,6 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     uint32_t max_slices = pl.n_po;                           // at least one patch octet per slice
     if (max_slices == 0) max_slices = 1;
     uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
-    pl.po_per_slice = (pl.n_po + slices - 1) / slices;
     pl.n_slices = slices;
     // units first_block, first_block + stride, ... below units_level
     pl.out_units = first_block < units_level ? (units_level - first_block + block_stride - 1) / block_stride : 0;

@@ -55,7 +55,6 @@ struct GgxPlan {
     int px, py;                    // output texels per thread = px*py; tile = 16px x 16py
     uint32_t tiles_x, tiles_y;     // tiles per face
     uint32_t n_patches;            // 6 * (w/patch) * (h/patch)
-    uint32_t patches_per_slice;
     uint32_t n_slices;
     size_t partial_bytes;          // [slice][out_count][4] double
     size_t prep_bytes_a;           // float4 per input texel (unit direction, |w|^-3)
@@ -74,7 +73,6 @@ struct GgxOctPlan {
     GgxLevel lv;
     uint32_t n_po;            // patch octets: 3 * (pw/2)^2
     uint32_t tw;              // edge of the output tile used for octet numbering
-    uint32_t po_per_slice;
     uint32_t n_slices;
     uint32_t reduce_groups;   // > 1: the slices are summed in this many groups first
     uint32_t out_units;       // 64-octet units this call covers
