@@ -6,8 +6,9 @@
 //     lanes, every lane keeps FP64 slope/bias sums, and a fixed-shape wavefront
 //     butterfly combines them, so a cell's value depends on
 //     (seed, cell, samples_sqrt) only.  No LDS.  The per-sample arithmetic keeps the
-//     reference's mix of float and double (angles and trig in double, BRDF terms
-//     in float).  The reference seeds std::mt19937 from std::random_device; here
+//     reference's mix of float and double where it matters (the cancelling
+//     cos(theta) in double, BRDF terms in float); the sine and cosine of phi and
+//     the fifth power run in float.  The reference seeds std::mt19937 from std::random_device; here
 //     the jitter is a counter-based hash of (seed, cell, sample) or the stratum
 //     midpoint.
 // rgbe_decode / rgbe_encode   src/util.cpp:93-145, one texel per thread.
@@ -59,13 +60,18 @@ __global__ __launch_bounds__(256) void brdf_lut_cells(uint32_t n_rough, uint32_t
         }
         const float ux = (float)((double)((float)sx / (float)samples_sqrt) + j1);
         const float uy = (float)((double)((float)sy / (float)samples_sqrt) + j2);
+        // cube.cpp:366-371 evaluates these in double and narrows each to float.  cos(theta) needs
+        // that: 1 + (a2 - 1) uy cancels for small roughness.  sin(theta) is the square root of a
+        // float-exact difference, and the sine and cosine of phi only have to be good to a few
+        // ulp (their products with sin(theta) are narrowed to float anyway), so those run in
+        // float: the double-precision sincos was most of the kernel's time.
         const float phi = (float)(2 * 3.14159265358979323846 * (double)ux);
         const float cos_t = (float)sqrt((1.0 - (double)uy) / (1.0 + ((double)a2 - 1.0) * (double)uy));
-        const float sin_t = (float)sqrt(1.0 - (double)(cos_t * cos_t));
-        double sphi, cphi;
-        sincos((double)phi, &sphi, &cphi);
-        const float hx = (float)((double)sin_t * cphi);
-        const float hy = (float)((double)sin_t * sphi);
+        const float sin_t = ref_sqrt(1.0f - cos_t * cos_t);
+        float sphi, cphi;
+        sincosf(phi, &sphi, &cphi);
+        const float hx = sin_t * cphi;
+        const float hy = sin_t * sphi;
         const float hz = cos_t;
         float vh = vx * hx;          // linear::dot with v.y == 0
         vh = vh + 0.0f * hy;
@@ -75,7 +81,8 @@ __global__ __launch_bounds__(256) void brdf_lut_cells(uint32_t n_rough, uint32_t
         if (lz > 0.0f) {
             const float g1l = lz / (lz * (1 - k) + k);
             const float g = g1l * g1v;
-            const float fres = powf(1 - vh, 5.0f);
+            const float omv = 1 - vh, omv2 = omv * omv;
+            const float fres = omv2 * omv2 * omv;       // (1 - v.h)^5, cube.cpp:375
             const float norm = vh / (hz * vz);
             slope += (double)(g * (1 - fres) * norm);
             bias += (double)(g * fres * norm);
