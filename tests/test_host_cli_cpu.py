@@ -114,3 +114,35 @@ def test_scene_mode_argument_errors():
     assert r.returncode != 0 and "missing argument to --scene" in r.stderr
     r = _run(CUBE, "--scene", "/nonexistent.s72")
     assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+def test_multi_gpu_bake_argument_handling():
+    """vulkan_renderer_amd.bake mirrors the tool's flags (cube.cpp:394-453)."""
+    import sys
+    r = subprocess.run([sys.executable, "-m", "vulkan_renderer_amd.bake", "--input-downscale", "3", "x.png"],
+                       capture_output=True, text=True, timeout=60, cwd=ROOT)
+    assert r.returncode != 0
+    assert "scale factor for --input-downscale should be a power of 2 >= 1" in r.stderr
+    r = subprocess.run([sys.executable, "-m", "vulkan_renderer_amd.bake"], capture_output=True, text=True, timeout=60, cwd=ROOT)
+    assert r.returncode != 0 and "file" in r.stderr
+
+
+def test_python_png_module_roundtrip(tmp_path):
+    import importlib
+    png = importlib.import_module("vulkan_renderer_amd.pngio")
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, size=(30, 17, 4), dtype=np.uint8)
+    img[5:20, 3:9] = img[5, 3]
+    for ct, filters in ((6, (0, 1, 2, 3, 4)), (2, (4, 3, 1))):
+        p = str(tmp_path / "a.png")
+        write_png(p, img, color_type=ct, filters=filters)
+        want = img.copy()
+        if ct == 2:
+            want[..., 3] = 255
+        np.testing.assert_array_equal(png.read_rgba8(p), want)
+    p = str(tmp_path / "b.png")
+    png.write_rgba8(p, img)
+    np.testing.assert_array_equal(read_png(p), img)
+    r = _run(ROUNDTRIP, p, str(tmp_path / "c.png"))          # and the C++ reader takes it
+    assert r.returncode == 0, r.stderr
+    np.testing.assert_array_equal(read_png(str(tmp_path / "c.png")), img)

@@ -114,3 +114,29 @@ def test_cube_cli_sampled_ggx(tmp_path, orc):
         got = read_png(str(tmp_path / ("sky.ggx%d.png" % m)))
         want = orc.rgbe_encode(orc.ggx_level_sampled(pyr, 64, ow, m, 2, 256, 0.5)).reshape(6 * ow, ow, 4)
         assert byte_identical_fraction(got, want) >= 0.999
+
+
+def test_multi_gpu_bake_writes_the_same_pixels(tmp_path):
+    """vulkan_renderer_amd.bake with three ranks (all on this box's one GPU, over gloo)
+    against bin/cube on one GPU: a texel does not depend on how the bake is sharded, so
+    the PNGs must hold identical pixels."""
+    import shutil
+    import sys
+    strip = vra.synth.hdr_environment(64, seed=21)
+    a, b = tmp_path / "one", tmp_path / "three"
+    a.mkdir()
+    b.mkdir()
+    write_png(str(a / "sky.png"), strip)
+    shutil.copy(str(a / "sky.png"), str(b / "sky.png"))
+    flags = ["--lambertian", "--ggx", "--cubemap-size", "8", "--input-downscale", "2"]
+    r = subprocess.run([CUBE] + flags + [str(a / "sky.png")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, IBL_BAKE_BACKEND="gloo", IBL_BAKE_SAME_DEVICE="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", "-m", "vulkan_renderer_amd.bake"]
+                       + flags + [str(b / "sky.png")], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    names = sorted(os.listdir(a))
+    assert names == sorted(os.listdir(b)) == ["sky.ggx1.png", "sky.ggx2.png", "sky.ggx3.png", "sky.lambertian.png", "sky.png"]
+    for name in names:
+        np.testing.assert_array_equal(read_png(str(a / name)), read_png(str(b / name)), err_msg=name)
