@@ -70,6 +70,8 @@ def lib():
         L.orc_rgbe_encode.restype = None
         L.orc_downscale.argtypes = [_f32p, _u32, _u32, _u32, _f32p]
         L.orc_downscale.restype = None
+        L.orc_vec_ops.argtypes = [_f32p, _f32p, _u32, _f32p]
+        L.orc_vec_ops.restype = None
         _lib = L
     return _lib
 
@@ -77,6 +79,17 @@ def lib():
 def normal_from(face, x, y, w, h):
     out = np.zeros(3, np.float32)
     lib().orc_normal_from(face, x, y, w, h, out)
+    return out
+
+
+def vec_ops(a, b):
+    """The oracle's vector helpers on n pairs of xyz triples: (n, 11) float32 rows of
+    dot(a,b), length2(a), normalize(a), a + b, 2*dot(a,b)*b - a."""
+    a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+    b = np.ascontiguousarray(b, np.float32).reshape(-1, 3)
+    assert a.shape == b.shape
+    out = np.zeros((a.shape[0], 11), np.float32)
+    lib().orc_vec_ops(a.reshape(-1), b.reshape(-1), a.shape[0], out.reshape(-1))
     return out
 
 

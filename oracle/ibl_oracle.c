@@ -60,6 +60,32 @@ static inline v3f add3(v3f a, v3f b) {
     return r;
 }
 
+/* 2.0f * dot(v, h) * h - v as cube.cpp:372 writes it with include/linear.hpp:79-90
+ * (scalar * Vec) and :51-57 (Vec - Vec); vh is dot3(v, h). */
+static inline v3f reflect3(v3f v, v3f h, float vh) {
+    float two_vh = 2.0f * vh;
+    v3f r = { two_vh * h.x - v.x, two_vh * h.y - v.y, two_vh * h.z - v.z };
+    return r;
+}
+
+/* The vector helpers above, laid open for the test that compares them bit for bit
+ * with the reference's own include/linear.hpp.  a and b hold n xyz triples; out
+ * receives 11 floats per pair: dot(a,b), length2(a), normalize(a), a + b,
+ * 2*dot(a,b)*b - a. */
+void orc_vec_ops(const float* a, const float* b, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; i++) {
+        v3f va = { a[3 * i], a[3 * i + 1], a[3 * i + 2] };
+        v3f vb = { b[3 * i], b[3 * i + 1], b[3 * i + 2] };
+        float* o = out + 11 * (size_t)i;
+        float d = dot3(va, vb);
+        v3f nn = normalize3(va), s = add3(va, vb), r = reflect3(va, vb, d);
+        o[0] = d; o[1] = dot3(va, va);
+        o[2] = nn.x; o[3] = nn.y; o[4] = nn.z;
+        o[5] = s.x; o[6] = s.y; o[7] = s.z;
+        o[8] = r.x; o[9] = r.y; o[10] = r.z;
+    }
+}
+
 /* getNormalFrom, src/utilities/cube.cpp:31-50.  s and t are evaluated in
  * double (the literals 0.5, 2.0, 1.0 are double) and rounded once to float. */
 static inline v3f normal_from(uint32_t face, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
@@ -334,8 +360,7 @@ static inline void lut_sample(float ux, float uy, float alpha, float a2, v3f v, 
     float sin_t = (float)sqrt(1.0 - (double)(cos_t * cos_t));
     v3f h = { (float)((double)sin_t * cos((double)phi)), (float)((double)sin_t * sin((double)phi)), cos_t };
     float vh = dot3(v, h);
-    float two_vh = 2.0f * vh;
-    v3f l = { two_vh * h.x - v.x, two_vh * h.y - v.y, two_vh * h.z - v.z };
+    v3f l = reflect3(v, h, vh);
     if (l.z > 0.0) {
         float k = alpha / 2;
         float g1l = l.z / (l.z * (1 - k) + k);

@@ -39,6 +39,31 @@ def test_texel_direction_table(orc):
     np.testing.assert_array_equal(unit[0, ::-1, :, 1], -unit[0, :, :, 1])
 
 
+def test_vector_helpers_are_ieee_binary32_in_the_header_order(orc):
+    """include/linear.hpp:42-122 written out with numpy float32 (IEEE, no fused
+    multiply-add): dot sums from 0 left to right, normalize is (1/sqrt(dot)) * v,
+    cube.cpp:372's reflection is (2*dot) * h - v."""
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((4096, 3)).astype(np.float32) * np.float32(3)
+    b = rng.standard_normal((4096, 3)).astype(np.float32)
+    a[:6] = np.eye(3, dtype=np.float32).repeat(2, 0) * np.float32([1, -1, 1, -1, 1, -1])[:, None]
+    got = orc.vec_ops(a, b)
+
+    def dot(u, v):
+        r = np.zeros(len(u), np.float32)
+        for i in range(3):
+            r = r + u[:, i] * v[:, i]
+        return r
+
+    d, l2 = dot(a, b), dot(a, a)
+    inv = np.float32(1) / np.sqrt(l2)
+    np.testing.assert_array_equal(got[:, 0], d)
+    np.testing.assert_array_equal(got[:, 1], l2)
+    np.testing.assert_array_equal(got[:, 2:5], inv[:, None] * a)
+    np.testing.assert_array_equal(got[:, 5:8], a + b)
+    np.testing.assert_array_equal(got[:, 8:11], (np.float32(2) * d)[:, None] * b - a)
+
+
 def test_constant_environment_known_answers(orc):
     # cube.cpp:112-126: the Lambertian weights sum to ~1 (quadrature error only);
     # cube.cpp:303-305: GGX divides by the summed weights, so a constant stays put.
