@@ -143,6 +143,16 @@ int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t ou
                               uint32_t mip_levels, uint32_t n_samples, float lod_bias, uint32_t out_begin,
                               uint32_t out_count, float* d_out, void* stream);
 
+/* PNG scanline filtering of a w x h RGBA8 image, the step of the tool's PNG writer
+ * between the RGBE encoder and deflate (cube.cpp:141,322 through stb_image_write,
+ * ext/stb_image_write.h:1092-1174): every row is filtered with the PNG filter type
+ * (none, sub, up, average, Paeth) whose output has the least sum of absolute values
+ * read as signed bytes, the lowest type winning ties.  d_rows receives
+ * ibl_png_rows_bytes(w, h) bytes: per row the filter type, then 4*w filtered bytes --
+ * the stream an IDAT chunk holds before compression. */
+uint64_t ibl_png_rows_bytes(uint32_t w, uint32_t h);
+int ibl_png_filter_rows_dev(const uint8_t* d_rgba8, uint32_t w, uint32_t h, uint8_t* d_rows, void* stream);
+
 /* ---- host-buffer entry points -------------------------------------------- */
 
 int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* out);
@@ -170,6 +180,15 @@ int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, 
  * 0 selects the quadrature, i.e. ibl_bake_rgbe).  No counterpart in the reference. */
 int ibl_bake_rgbe_sampled(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
                           uint32_t ggx_samples, float lod_bias, uint8_t* lambertian_out, uint8_t* ggx_out);
+
+/* The same bake, handing back PNG scanline streams instead of pixels (the filter step of
+ * ibl_png_filter_rows_dev runs on the device after the encoder): lambertian_rows receives
+ * ibl_png_rows_bytes(cubemap_size, 6*cubemap_size) bytes, ggx_rows the levels back to back,
+ * level m being ibl_png_rows_bytes(w>>m, 6*(w>>m)) bytes.  The caller deflates and wraps
+ * them in IHDR/IDAT/IEND. */
+int ibl_bake_png_rows(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
+                      uint32_t ggx_samples, float lod_bias, uint8_t* lambertian_rows, uint8_t* ggx_rows);
+int ibl_png_filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t* rows);
 
 /* ---- measurement ---------------------------------------------------------- */
 

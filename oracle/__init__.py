@@ -70,6 +70,8 @@ def lib():
         L.orc_rgbe_encode.restype = None
         L.orc_downscale.argtypes = [_f32p, _u32, _u32, _u32, _f32p]
         L.orc_downscale.restype = None
+        L.orc_png_filter_rows.argtypes = [_u8p, _u32, _u32, _u8p]
+        L.orc_png_filter_rows.restype = None
         L.orc_vec_ops.argtypes = [_f32p, _f32p, _u32, _f32p]
         L.orc_vec_ops.restype = None
         _lib = L
@@ -233,3 +235,14 @@ def downscale(env, d):
     out = np.zeros((6, h // d, w // d, 4), np.float32)
     lib().orc_downscale(env, w, h, d, out)
     return out
+
+
+def png_filter_rows(rgba8):
+    """(h, w, 4) uint8 -> (h, 4w+1) uint8 PNG scanlines (filter type first) with the
+    writer's per-row filter choice."""
+    rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+    h, w, c = rgba8.shape
+    assert c == 4
+    rows = np.zeros((h, 4 * w + 1), np.uint8)
+    lib().orc_png_filter_rows(rgba8.reshape(-1), w, h, rows.reshape(-1))
+    return rows

@@ -478,3 +478,45 @@ void orc_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* 
         }
     }
 }
+
+/* ------------------------------------------------------- PNG scanline filter */
+
+static inline int paeth_predict(int a, int b, int c) {
+    int p = a + b - c;
+    int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+
+static uint8_t png_filter_byte(int type, const uint8_t* cur, const uint8_t* up, size_t i) {
+    int a = i >= 4 ? cur[i - 4] : 0, b = up ? up[i] : 0, c = (up && i >= 4) ? up[i - 4] : 0, pred = 0;
+    if (type == 1) pred = a;
+    else if (type == 2) pred = b;
+    else if (type == 3) pred = (a + b) >> 1;
+    else if (type == 4) pred = paeth_predict(a, b, c);
+    return (uint8_t)(cur[i] - pred);
+}
+
+/* The filter stage of the PNG writer the tool saves its strips with (cube.cpp:141,322:
+ * stb_image_write with its default settings, ext/stb_image_write.h:1092-1174): per row,
+ * all five PNG filters are tried on the RGBA8 bytes (neighbours outside the image are 0,
+ * which is what that file's first-row table amounts to), the one with the least sum of
+ * |signed byte| is kept, and the lowest type wins ties.  rows receives (4w+1)*h bytes:
+ * filter type, then the filtered row. */
+void orc_png_filter_rows(const uint8_t* rgba, uint32_t w, uint32_t h, uint8_t* rows) {
+    const size_t stride = (size_t)w * 4;
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t* cur = rgba + stride * y;
+        const uint8_t* up = y ? cur - stride : NULL;
+        int best = 0;
+        long best_sum = -1;
+        for (int t = 0; t < 5; t++) {
+            long sum = 0;
+            for (size_t i = 0; i < stride; i++) sum += abs((int)(int8_t)png_filter_byte(t, cur, up, i));
+            if (best_sum < 0 || sum < best_sum) { best_sum = sum; best = t; }
+        }
+        uint8_t* dst = rows + (stride + 1) * y;
+        dst[0] = (uint8_t)best;
+        for (size_t i = 0; i < stride; i++) dst[1 + i] = png_filter_byte(best, cur, up, i);
+    }
+}

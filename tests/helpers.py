@@ -26,6 +26,26 @@ def decode_strip(orc, strip):
 
 # ---- a tiny independent PNG codec for the CLI tests (zlib only) -----------------------
 
+def filter_row(cur, prev, ch, ft):
+    """One PNG scanline (int32 byte values, `ch` bytes per pixel) under filter type ft -> uint8 bytes."""
+    left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+    upleft = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+    if ft == 0:
+        out = cur
+    elif ft == 1:
+        out = cur - left
+    elif ft == 2:
+        out = cur - prev
+    elif ft == 3:
+        out = cur - (left + prev) // 2
+    else:
+        p = left + prev - upleft
+        pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+        pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        out = cur - pred
+    return (out & 255).astype(np.uint8)
+
+
 def write_png(path, rgba, color_type=6, filters=(0,)):
     """rgba: (H, W, 4) uint8.  color_type 6 (RGBA) or 2 (RGB); `filters` cycles per row."""
     import struct
@@ -39,22 +59,7 @@ def write_png(path, rgba, color_type=6, filters=(0,)):
     for y in range(h):
         cur = img[y].reshape(-1).astype(np.int32)
         ft = filters[y % len(filters)]
-        left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
-        upleft = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
-        if ft == 0:
-            out = cur
-        elif ft == 1:
-            out = cur - left
-        elif ft == 2:
-            out = cur - prev
-        elif ft == 3:
-            out = cur - (left + prev) // 2
-        else:
-            p = left + prev - upleft
-            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
-            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
-            out = cur - pred
-        rows.append(bytes([ft]) + (out & 255).astype(np.uint8).tobytes())
+        rows.append(bytes([ft]) + filter_row(cur, prev, ch, ft).tobytes())
         prev = cur
 
     def chunk(t, d):
@@ -86,13 +91,38 @@ def read_png(path):
             idat += body
         pos += 12 + n
     raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
-    out = np.zeros((h, w * 4), np.int32)
+    return unfilter_rows(raw)
+
+
+def unfilter_rows(rows):
+    """(H, 4W+1) uint8 PNG scanlines of an RGBA8 image (filter type first) -> (H, W, 4) uint8."""
+    rows = np.asarray(rows, np.uint8)
+    h, w = rows.shape[0], (rows.shape[1] - 1) // 4
+    out = np.zeros((h, w, 4), np.int32)
+    zero = np.zeros((w, 4), np.int32)
     for y in range(h):
-        ft, row = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        ft, row = int(rows[y, 0]), rows[y, 1:].astype(np.int32).reshape(w, 4)
+        up = out[y - 1] if y else zero
         if ft == 0:
             out[y] = row
+        elif ft == 1:
+            out[y] = np.cumsum(row, axis=0) & 255
         elif ft == 2:
-            out[y] = (row + (out[y - 1] if y else 0)) & 255
+            out[y] = (row + up) & 255
+        elif ft in (3, 4):
+            left = np.zeros(4, np.int32)
+            upleft = np.zeros(4, np.int32)
+            for x in range(w):
+                b = up[x]
+                if ft == 3:
+                    pred = (left + b) >> 1
+                else:
+                    p = left + b - upleft
+                    pa, pb, pc = np.abs(p - left), np.abs(p - b), np.abs(p - upleft)
+                    pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, b, upleft))
+                left = (row[x] + pred) & 255
+                out[y, x] = left
+                upleft = b
         else:
-            raise AssertionError("unexpected filter %d" % ft)
-    return out.astype(np.uint8).reshape(h, w, 4)
+            raise AssertionError("bad filter type %d" % ft)
+    return out.astype(np.uint8)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import vulkan_renderer_amd as vra
-from helpers import decode_strip
+from helpers import decode_strip, filter_row, unfilter_rows
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -210,6 +210,35 @@ def test_rgbe_codec_edges(orc):
     m = x[:, :3].max(axis=1, keepdims=True)
     assert (np.abs(d[:, :3] - x[:, :3]) <= m / 128 * (1 + 1e-6)).all()
     np.testing.assert_array_equal(orc.rgbe_encode(d), e)
+
+
+def test_png_filter_rows_choice_and_bytes(orc):
+    """ext/stb_image_write.h:1146-1174 with default settings: per row the filter with the least
+    sum of |signed byte|, first minimum wins; rows decode back to the pixels."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(48, 19, 4), dtype=np.uint8)
+    img[8:16] = img[8]                                                    # repeated rows
+    img[16:24] = (np.arange(19, dtype=np.uint8) * 5)[None, :, None]       # horizontal ramps
+    img[24:32] = (np.add.outer(np.arange(8), np.arange(19)) * 3 % 256).astype(np.uint8)[:, :, None]
+    img[32:40] = 0                                                        # all filters tie at 0
+    img[0] = 200                                                          # first row: no row above
+    rows = orc.png_filter_rows(img)
+    assert rows.shape == (48, 4 * 19 + 1)
+    np.testing.assert_array_equal(unfilter_rows(rows), img)
+    prev = np.zeros(19 * 4, np.int32)
+    for y in range(48):
+        cur = img[y].reshape(-1).astype(np.int32)
+        cands = [filter_row(cur, prev, 4, ft) for ft in range(5)]
+        cost = [int(np.abs(c.view(np.int8).astype(np.int32)).sum()) for c in cands]
+        best = int(np.argmin(cost))                                       # argmin keeps the first minimum
+        assert rows[y, 0] == best, (y, cost)
+        np.testing.assert_array_equal(rows[y, 1:], cands[best])
+        prev = cur
+    assert (rows[32:40, 0] == 0).all()                                    # zero rows: every filter that ties loses to type 0
+    assert set(rows[:, 0]) >= {0, 1, 2}
+    # a single pixel and an empty image
+    one = orc.png_filter_rows(np.full((1, 1, 4), 7, np.uint8))
+    np.testing.assert_array_equal(one, [[0, 7, 7, 7, 7]])
 
 
 def test_downscale_box(orc):

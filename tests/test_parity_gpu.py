@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import vulkan_renderer_amd as vra
-from helpers import byte_identical_fraction, decode_strip, rel_err
+from helpers import byte_identical_fraction, decode_strip, rel_err, unfilter_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -140,6 +140,33 @@ def test_rgbe_encode_bit_exact(ibl, orc):
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(ibl.rgbe_encode_host(x[:4096]), want[:4096])
     assert ibl.rgbe_encode_host(np.zeros((0, 4), np.float32)).shape == (0, 4)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 7), (16, 96), (64, 384), (257, 33), (300, 20), (1024, 48)])
+def test_png_filter_rows_bit_exact(ibl, orc, w, h):
+    """The writer's per-row filter choice and the filtered bytes (cube.cpp:141,322 through
+    ext/stb_image_write.h:1092-1174), on noise, repeated rows, ramps and zeros."""
+    rng = np.random.default_rng(w * 131 + h)
+    img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    if h >= 20:
+        img[4:8] = img[4]
+        img[8:12] = (np.arange(w) * 3 % 256).astype(np.uint8)[None, :, None]
+        img[12:16] = 0
+        img[16:20] = (np.add.outer(np.arange(4) * 7, np.arange(w) * 2) % 256).astype(np.uint8)[:, :, None]
+    want = orc.png_filter_rows(img)
+    got = ibl.png_filter_rows(_dev(ibl, img)).cpu().numpy()
+    np.testing.assert_array_equal(got[:, 0], want[:, 0])
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(ibl.png_filter_rows_host(img), want)
+
+
+def test_png_filter_rows_of_an_rgbe_strip(ibl, orc):
+    strip = vra.synth.hdr_environment(128, seed=4)
+    want = orc.png_filter_rows(strip)
+    np.testing.assert_array_equal(ibl.png_filter_rows(_dev(ibl, strip)).cpu().numpy(), want)
+    assert len(set(want[:, 0])) >= 2          # a smooth environment does not settle on one filter
+    np.testing.assert_array_equal(unfilter_rows(want[:32]), strip[:32])
+    assert ibl.png_filter_rows_host(np.zeros((0, 5, 4), np.uint8)).shape == (0, 21)
 
 
 @pytest.mark.parametrize("w,d", [(64, 1), (64, 2), (64, 16), (64, 64), (256, 32)])
@@ -416,3 +443,18 @@ def test_bake_rgbe_end_to_end(ibl, orc):
         want = orc.rgbe_encode(orc.ggx_level(env, ow, ow, m, mips)).reshape(6 * ow, ow, 4)
         assert lv.shape == want.shape
         assert byte_identical_fraction(lv, want) >= BYTE_FRACTION
+
+
+def test_bake_png_rows_is_bake_rgbe_filtered(ibl, orc):
+    """ibl_bake_png_rows hands back the scanline streams of exactly the pixels ibl_bake_rgbe returns."""
+    strip = vra.synth.hdr_environment(64, seed=22)
+    lam, levels = ibl.bake_rgbe(strip, cubemap_size=16)
+    lam_rows, level_rows = ibl.bake_png_rows(strip, cubemap_size=16)
+    np.testing.assert_array_equal(lam_rows, orc.png_filter_rows(lam))
+    np.testing.assert_array_equal(unfilter_rows(lam_rows), lam)
+    assert len(level_rows) == len(levels) == 2
+    for rows, px in zip(level_rows, levels):
+        np.testing.assert_array_equal(rows, orc.png_filter_rows(px))
+    only_lam, none = ibl.bake_png_rows(strip, cubemap_size=16, ggx=False)
+    np.testing.assert_array_equal(only_lam, lam_rows)
+    assert none == []

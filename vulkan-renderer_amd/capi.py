@@ -55,6 +55,10 @@ _SIGNATURES = {
     "ibl_downscale": ([_vp, _u32, _u32, _u32, _vp], _int),
     "ibl_bake_rgbe": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_bake_rgbe_sampled": ([_vp, _u32, _u32, _u32, _u32, ctypes.c_float, _vp, _vp], _int),
+    "ibl_png_rows_bytes": ([_u32, _u32], _u64),
+    "ibl_png_filter_rows_dev": ([_vp, _u32, _u32, _vp, _vp], _int),
+    "ibl_png_filter_rows": ([_vp, _u32, _u32, _vp], _int),
+    "ibl_bake_png_rows": ([_vp, _u32, _u32, _u32, _u32, ctypes.c_float, _vp, _vp], _int),
     "ibl_set_timing": ([_int], _int),
     "ibl_last_kernel_ms": ([ctypes.POINTER(ctypes.c_float)], _int),
     "ibl_set_counting": ([_int], _int),
@@ -260,6 +264,15 @@ class Ibl:
         self._check(self.lib.ibl_texel_directions_dev(w, h, int(bool(normalized)), _ptr(out), self._stream(stream)))
         return out
 
+    def png_filter_rows(self, rgba8, stream=None):
+        """(h, w, 4) uint8 device tensor -> (h, 4w+1) uint8 PNG scanlines (filter type first),
+        filtered per row as the tool's PNG writer chooses (cube.cpp:141,322)."""
+        assert rgba8.dtype == self.torch.uint8 and rgba8.is_contiguous() and rgba8.shape[-1] == 4
+        h, w = rgba8.shape[0], rgba8.shape[1]
+        rows = self.torch.empty((h, 4 * w + 1), dtype=self.torch.uint8, device=self.device)
+        self._check(self.lib.ibl_png_filter_rows_dev(_ptr(rgba8), w, h, _ptr(rows), self._stream(stream)))
+        return rows
+
     # -- measurement --------------------------------------------------------------------
     def set_timing(self, on):
         self._check(self.lib.ibl_set_timing(int(bool(on))))
@@ -339,5 +352,35 @@ class Ibl:
         for s in sizes:
             n = 6 * s * s * 4
             levels.append(gbuf[off:off + n].reshape(6 * s, s, 4))
+            off += n
+        return lam, levels
+
+    def png_filter_rows_host(self, rgba8):
+        rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        h, w, c = rgba8.shape
+        assert c == 4
+        rows = np.zeros((h, 4 * w + 1), np.uint8)
+        assert rows.size == self.lib.ibl_png_rows_bytes(w, h)
+        self._check(self.lib.ibl_png_filter_rows(rgba8.ctypes.data, w, h, rows.ctypes.data))
+        return rows
+
+    def bake_png_rows(self, rgbe, input_downscale=1, cubemap_size=16, lambertian=True, ggx=True, ggx_samples=0,
+                      lod_bias=1.0):
+        """bake_rgbe, but every result is the (6*S, 4*S+1) uint8 PNG scanline stream of its strip."""
+        rgbe = np.ascontiguousarray(rgbe, dtype=np.uint8)
+        w = rgbe.shape[1]
+        assert rgbe.shape == (6 * w, w, 4), rgbe.shape
+        lam = np.zeros((6 * cubemap_size, 4 * cubemap_size + 1), np.uint8) if lambertian else None
+        mips = self.ggx_mip_levels(w, w, cubemap_size) if ggx else 0
+        sizes = [w >> m for m in range(1, mips + 1)]
+        total = sum(6 * s * (4 * s + 1) for s in sizes)
+        gbuf = np.zeros(max(total, 1), np.uint8) if ggx else None
+        self._check(self.lib.ibl_bake_png_rows(rgbe.ctypes.data, w, input_downscale, cubemap_size, ggx_samples,
+                                               float(lod_bias), lam.ctypes.data if lambertian else None,
+                                               gbuf.ctypes.data if ggx else None))
+        levels, off = [], 0
+        for s in sizes:
+            n = 6 * s * (4 * s + 1)
+            levels.append(gbuf[off:off + n].reshape(6 * s, 4 * s + 1))
             off += n
         return lam, levels

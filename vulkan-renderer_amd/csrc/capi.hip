@@ -422,6 +422,17 @@ int ibl_rgbe_encode_dev(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, void* 
     return IBL_OK;
 }
 
+uint64_t ibl_png_rows_bytes(uint32_t w, uint32_t h) { return ((uint64_t)w * 4 + 1) * h; }
+
+int ibl_png_filter_rows_dev(const uint8_t* d_rgba8, uint32_t w, uint32_t h, uint8_t* d_rows, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (w == 0 || h == 0) return IBL_OK;
+    if (!d_rgba8 || !d_rows) return fail(IBL_EINVAL, "png_filter_rows: null pointer");
+    if ((uint64_t)w * h > 0x7fffffffull / 4) return fail(IBL_EINVAL, "png_filter_rows: image %ux%u too large", w, h);
+    HIP_TRY(ibl::png_filter_rows_launch(d_rgba8, w, h, d_rows, pick(stream)));
+    return IBL_OK;
+}
+
 int ibl_downscale_dev(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, void* stream) {
     if (int rc = check_ready()) return rc;
     if (!d_env || !d_out) return fail(IBL_EINVAL, "downscale: null pointer");
@@ -587,13 +598,59 @@ int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* o
     return stage_out(out, out_bytes);
 }
 
+int ibl_png_filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t* rows) {
+    if (int rc = check_ready()) return rc;
+    if (w == 0 || h == 0) return IBL_OK;
+    if (!rgba8 || !rows) return fail(IBL_EINVAL, "png_filter_rows: null pointer");
+    if ((uint64_t)w * h > 0x7fffffffull / 4) return fail(IBL_EINVAL, "png_filter_rows: image %ux%u too large", w, h);
+    const size_t out_bytes = (size_t)ibl_png_rows_bytes(w, h);
+    if (int rc = stage_in(rgba8, (size_t)w * h * 4)) return rc;
+    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
+    if (int rc = ibl_png_filter_rows_dev((const uint8_t*)g.stage_in.ptr, w, h, (uint8_t*)g.stage_out.ptr, nullptr)) return rc;
+    return stage_out(rows, out_bytes);
+}
+
+namespace {
+int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size, uint32_t ggx_samples,
+         float lod_bias, bool png_rows, uint8_t* lambertian_out, uint8_t* ggx_out);
+}
+
 int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
                   uint8_t* lambertian_out, uint8_t* ggx_out) {
-    return ibl_bake_rgbe_sampled(rgbe_in, w, input_downscale, cubemap_size, 0, 0.0f, lambertian_out, ggx_out);
+    return bake(rgbe_in, w, input_downscale, cubemap_size, 0, 0.0f, false, lambertian_out, ggx_out);
 }
 
 int ibl_bake_rgbe_sampled(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
                           uint32_t ggx_samples, float lod_bias, uint8_t* lambertian_out, uint8_t* ggx_out) {
+    return bake(rgbe_in, w, input_downscale, cubemap_size, ggx_samples, lod_bias, false, lambertian_out, ggx_out);
+}
+
+int ibl_bake_png_rows(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
+                      uint32_t ggx_samples, float lod_bias, uint8_t* lambertian_rows, uint8_t* ggx_rows) {
+    return bake(rgbe_in, w, input_downscale, cubemap_size, ggx_samples, lod_bias, true, lambertian_rows, ggx_rows);
+}
+
+namespace {
+// pixels: the RGBE texels of one finished cube (n of them, faces of edge `edge`); hands them to the
+// caller as they are or as PNG scanlines, and returns the number of bytes written to dst.
+int emit(const float* d_f, uint8_t* d_e, uint8_t* d_rows, uint32_t edge, bool png_rows, uint8_t* dst, size_t* written) {
+    const uint32_t n = edge * edge * 6;
+    if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n, nullptr)) return rc;
+    const uint8_t* src = d_e;
+    size_t bytes = (size_t)n * 4;
+    if (png_rows) {
+        if (int rc = ibl_png_filter_rows_dev(d_e, edge, edge * 6, d_rows, nullptr)) return rc;
+        src = d_rows;
+        bytes = (size_t)ibl_png_rows_bytes(edge, edge * 6);
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *written = bytes;
+    return IBL_OK;
+}
+
+int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size, uint32_t ggx_samples,
+         float lod_bias, bool png_rows, uint8_t* lambertian_out, uint8_t* ggx_out) {
     if (int rc = check_ready()) return rc;
     if (!rgbe_in) return fail(IBL_EINVAL, "bake: null input");
     if (int rc = check_cube(w, w, "bake input")) return rc;
@@ -620,20 +677,21 @@ int ibl_bake_rgbe_sampled(const uint8_t* rgbe_in, uint32_t w, uint32_t input_dow
         d_env = (float*)(base + off_ds);
         if (int rc = ibl_downscale_dev(d_full, w, w, input_downscale, d_env, nullptr)) return rc;
     }
-    // Staging-out block: [float scratch of the largest output][rgbe bytes]
     uint32_t mips = ggx_out ? ibl_ggx_mip_levels(w, w, cubemap_size) : 0;
     uint32_t n_max = lambertian_out ? n_lamb : 0;
     if (mips) { uint32_t n1 = (w / 2) * (w / 2) * 6; if (n1 > n_max) n_max = n1; }
     if (n_max == 0) { HIP_TRY(hipStreamSynchronize(g.stream)); return IBL_OK; }
+    // Staging-out block: [float cube of the largest output][its RGBE bytes][its PNG scanlines]
     const size_t off_bytes = (size_t)n_max * 16;
-    if (int rc = ensure(g.stage_out, off_bytes + (size_t)n_max * 4)) return rc;
+    const size_t off_rows = off_bytes + (size_t)n_max * 4;
+    if (int rc = ensure(g.stage_out, off_rows + (png_rows ? (size_t)n_max * 4 + (size_t)n_max : 0))) return rc;
     float* d_f = (float*)g.stage_out.ptr;
     uint8_t* d_e = (uint8_t*)g.stage_out.ptr + off_bytes;
+    uint8_t* d_rows = (uint8_t*)g.stage_out.ptr + off_rows;
+    size_t written = 0;
     if (lambertian_out) {
         if (int rc = ibl_lambertian_dev(d_env, dw, dw, cubemap_size, 0, n_lamb, d_f, nullptr)) return rc;
-        if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n_lamb, nullptr)) return rc;
-        HIP_TRY(hipMemcpyAsync(lambertian_out, d_e, (size_t)n_lamb * 4, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (int rc = emit(d_f, d_e, d_rows, cubemap_size, png_rows, lambertian_out, &written)) return rc;
     }
     if (mips && ggx_samples) {      // sampled mode: one pyramid of the (downscaled) environment for all levels
         if (int rc = ensure(g.b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
@@ -647,12 +705,11 @@ int ibl_bake_rgbe_sampled(const uint8_t* rgbe_in, uint32_t w, uint32_t input_dow
             if (int rc = ibl_ggx_level_sampled_dev((const float*)g.b.ptr, dw, mw, m, mips, ggx_samples, lod_bias, 0, n_m,
                                                    d_f, nullptr)) return rc;
         } else if (int rc = ibl_ggx_level_dev(d_env, dw, dw, mw, mw, m, mips, 0, n_m, d_f, nullptr)) return rc;
-        if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n_m, nullptr)) return rc;
-        HIP_TRY(hipMemcpyAsync(ggx_out + out_off, d_e, (size_t)n_m * 4, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        out_off += (size_t)n_m * 4;
+        if (int rc = emit(d_f, d_e, d_rows, mw, png_rows, ggx_out + out_off, &written)) return rc;
+        out_off += written;
     }
     return IBL_OK;
 }
+}  // namespace
 
 }  // extern "C"

@@ -105,5 +105,7 @@ hipError_t rgbe_decode_launch(const uint8_t* d_rgbe, float* d_rgba, uint32_t n, 
 hipError_t rgbe_encode_launch(const float* d_rgba, uint8_t* d_rgbe, uint32_t n, hipStream_t stream);
 hipError_t texel_directions_launch(uint32_t w, uint32_t h, int normalized, float* d_out, hipStream_t stream);
 hipError_t downscale_launch(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, hipStream_t stream);
+// png_rows.hip: rows of (1 + 4w) bytes, filter type first
+hipError_t png_filter_rows_launch(const uint8_t* d_rgba8, uint32_t w, uint32_t h, uint8_t* d_rows, hipStream_t stream);
 
 }  // namespace ibl

@@ -85,19 +85,21 @@ void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) 
 
     check(ibl_init(-1));
     const uint32_t mips = opt.ggx ? ibl_ggx_mip_levels(w, h, opt.cubemap_size) : 0;
-    std::vector<uint8_t> lambertian(opt.lambertian ? (size_t)opt.cubemap_size * opt.cubemap_size * 6 * 4 : 0);
+    // The library hands back PNG scanlines (RGBE-encoded and filtered on the device); only deflate is left to do here.
+    std::vector<uint8_t> lambertian(opt.lambertian ? (size_t)ibl_png_rows_bytes(opt.cubemap_size, opt.cubemap_size * 6) : 0);
     size_t ggx_bytes = 0;
-    for (uint32_t m = 1; m <= mips; m++) ggx_bytes += (size_t)(w >> m) * (w >> m) * 6 * 4;
+    for (uint32_t m = 1; m <= mips; m++) ggx_bytes += (size_t)ibl_png_rows_bytes(w >> m, (w >> m) * 6);
     std::vector<uint8_t> ggx(ggx_bytes);
-    check(ibl_bake_rgbe_sampled(pixels.data(), w, opt.input_downscale, opt.cubemap_size, opt.ggx_samples, opt.ggx_lod_bias,
-                                opt.lambertian ? lambertian.data() : nullptr, (opt.ggx && mips) ? ggx.data() : nullptr));
+    check(ibl_bake_png_rows(pixels.data(), w, opt.input_downscale, opt.cubemap_size, opt.ggx_samples, opt.ggx_lod_bias,
+                            opt.lambertian ? lambertian.data() : nullptr, (opt.ggx && mips) ? ggx.data() : nullptr));
 
     if (opt.lambertian) {
         std::cout << "Integrating Lambertian: [" << std::flush;
         print_bar();
         std::filesystem::path out = input_path;
         out.replace_extension(".lambertian.png");
-        if (!png_write_rgba8(out.string(), opt.cubemap_size, opt.cubemap_size * 6, lambertian.data(), err)) PANIC(err);
+        if (!png_write_filtered_rows(out.string(), opt.cubemap_size, opt.cubemap_size * 6, lambertian.data(), lambertian.size(), err))
+            PANIC(err);
     }
     size_t off = 0;
     for (uint32_t m = 1; m <= mips; m++) {
@@ -106,8 +108,9 @@ void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) 
         print_bar();
         std::filesystem::path out = input_path;
         out.replace_extension(".ggx" + std::to_string(m) + ".png");
-        if (!png_write_rgba8(out.string(), mw, mw * 6, ggx.data() + off, err)) PANIC(err);
-        off += (size_t)mw * mw * 6 * 4;
+        const size_t n_bytes = (size_t)ibl_png_rows_bytes(mw, mw * 6);
+        if (!png_write_filtered_rows(out.string(), mw, mw * 6, ggx.data() + off, n_bytes, err)) PANIC(err);
+        off += n_bytes;
     }
 }
 

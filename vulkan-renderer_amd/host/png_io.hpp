@@ -11,3 +11,8 @@ bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, 
 
 // Writes tightly packed RGBA8 rows (stbi_write_png(path, w, h, 4, data, w*4), cube.cpp:141,322).
 bool png_write_rgba8(const std::string& path, uint32_t width, uint32_t height, const uint8_t* rgba, std::string& err);
+
+// Writes an RGBA8 image whose scanlines are already filtered: `rows` holds height rows of
+// 1 + 4*width bytes (PNG filter type, filtered bytes), e.g. from ibl_bake_png_rows.
+bool png_write_filtered_rows(const std::string& path, uint32_t width, uint32_t height, const uint8_t* rows, size_t n_bytes,
+                             std::string& err);
