@@ -176,6 +176,46 @@ def test_lut_statistically_matches_committed_table(orc):
     assert np.abs(d[:, 0]).max() < 1e-4 and np.abs(d[:, 1]).max() < 2e-4
 
 
+def _noise_stats(table, conv):
+    d = np.asarray(table, np.float64) - conv
+    return (d[..., 0].mean(), d[..., 1].mean(), np.sqrt((d[..., 0] ** 2).mean()), np.sqrt((d[..., 1] ** 2).mean()),
+            (np.abs(d) < 1e-4).all(-1).mean())
+
+
+def test_committed_table_is_noise_around_the_converged_integral():
+    """tests/golden/ggx_lut_converged.npy is a float64 quadrature of the integral that
+    cube.cpp:346-385 estimates (made by make_lut_converged.py, independent of the sampling
+    code).  The reference's committed include/ggx_lut.inl differs from it by zero-mean
+    noise: the mean over the 65 536 cells is within 4 standard errors of 0, which pins the
+    integrand (not just its noise level) to about 1e-5 of the table's scale."""
+    conv = np.load(os.path.join(GOLDEN, "ggx_lut_converged.npy")).astype(np.float64)
+    ref = np.load(os.path.join(GOLDEN, "ggx_lut_committed.npy"))
+    assert conv.shape == ref.shape == (256, 256, 2)
+    m_s, m_b, r_s, r_b, within = _noise_stats(ref, conv)
+    assert 3e-4 < r_s < 7e-4 and 1e-5 < r_b < 3e-5
+    assert abs(m_s) < 4 * r_s / 256 and abs(m_b) < 4 * r_b / 256
+    assert 0.6 < within < 0.8
+    # the mirror-like row is exact to the file's six printed digits away from grazing views
+    assert np.abs(ref[0, 8:] - conv[0, 8:]).max() < 1.5e-6 and np.abs(ref[0] - conv[0]).max() < 1e-4
+    # analytic limit of that row: h = n, l = mirror image of v, so slope + bias = G1(v)^2
+    cv = (np.arange(256) + 0.5) / 256
+    k = 0.5 * (0.5 / 256) ** 2
+    assert np.abs(conv[0].sum(-1) - (cv / (cv * (1 - k) + k)) ** 2).max() < 1e-7
+
+
+def test_oracle_lut_rows_against_the_converged_integral(orc):
+    """The oracle at the reference's density (256 x 256 strata) on four roughness rows: the
+    same zero-mean noise around the converged values as the reference's own table shows."""
+    conv = np.load(os.path.join(GOLDEN, "ggx_lut_converged.npy")).astype(np.float64)
+    ref = np.load(os.path.join(GOLDEN, "ggx_lut_committed.npy")).astype(np.float64)
+    for row in (0, 64, 128, 255):
+        got = orc.brdf_lut(256, 256, 256, seed=9, mode=orc.MODE_COUNTER, cell_begin=row * 256, cell_count=256)[row]
+        d, d_ref = got - conv[row], ref[row] - conv[row]
+        rms, rms_ref = np.sqrt((d ** 2).mean(0)), np.sqrt((d_ref ** 2).mean(0))
+        assert (rms < 2.0 * rms_ref + 1e-6).all(), (row, rms, rms_ref)
+        assert (np.abs(d.mean(0)) < 4 * rms / 16 + 1e-7).all(), (row, d.mean(0), rms)
+
+
 def test_lut_midpoint_converges_to_jittered(orc):
     # the deterministic quadrature and the jittered estimate agree within noise
     a = orc.brdf_lut(8, 8, 512, mode=orc.MODE_MIDPOINT)
