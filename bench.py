@@ -36,7 +36,6 @@ if ROOT not in sys.path:
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3     # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
 FLOP_PER_LAMBERTIAN_PAIR = 12       # dot 5, max 1, 3 FMA 6
-# the octet kernel issues 3 mul + 8 add + 168 FMA + 1 idle pattern per 64 pairs
 # what the octet kernel issues per 64 pairs when every wave agrees on the sign of each pattern pair
 # (3 mul, 2 add, 3 tests, 4 clamps, 96 FMAs); waves that straddle a sign change issue up to 168 FMAs
 EXECUTED_FLOP_PER_LAMBERTIAN_PAIR = (3 + 2 + 3 + 4 + 2 * 96) / 64.0
