@@ -17,7 +17,10 @@
  *   - "*_dev" functions take DEVICE pointers, enqueue on `stream` (a hipStream_t;
  *     NULL = the HIP default stream) and do not synchronise.  They use a
  *     per-device workspace the library owns, so calls on one device must not
- *     overlap in time.
+ *     overlap in time: issue them on one stream, or order streams with events.
+ *   - The library is bound to one device per process (ibl_init) and keeps its
+ *     state without locks, like the single-threaded tool it serves
+ *     (cube.cpp:392-517): callers with several threads serialise their calls.
  *   - The functions without the suffix take HOST pointers, copy in, run, copy out
  *     and block; they are what a C++ host that used to call the reference
  *     functions calls instead.

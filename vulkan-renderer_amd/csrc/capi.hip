@@ -134,7 +134,11 @@ int ibl_init(int device) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
     HIP_TRY(hipEventCreate(&g.ev0));
-    HIP_TRY(hipEventCreate(&g.ev1));
+    if (hipError_t e1 = hipEventCreate(&g.ev1); e1 != hipSuccess) {
+        (void)hipEventDestroy(g.ev0);
+        g.ev0 = nullptr;
+        return fail(IBL_EHIP, "hipEventCreate: %s", hipGetErrorString(e1));
+    }
     g.device = device;
     g.ready = true;
     return IBL_OK;
@@ -659,6 +663,7 @@ int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t 
     if (input_downscale > w || w % input_downscale != 0)
         return fail(IBL_EINVAL, "bake: downscale %u does not divide the face width %u", input_downscale, w);
     if (cubemap_size == 0) return fail(IBL_EINVAL, "bake: cubemap size 0");
+    if (lambertian_out) if (int rc = check_cube(cubemap_size, cubemap_size, "bake lambertian output")) return rc;
     const uint32_t n_full = w * w * 6;
     const uint32_t dw = w / input_downscale;
     const uint32_t n_ds = dw * dw * 6;
