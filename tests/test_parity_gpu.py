@@ -376,6 +376,36 @@ def test_ggx_rejects_small_and_bad_levels(ibl, orc):
     assert float(out.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("w", [4096, pytest.param(8192, marks=pytest.mark.skipif(
+    os.environ.get("IBL_TEST_HUGE") != "1", reason="6.4 GB environment; set IBL_TEST_HUGE=1"))])
+def test_largest_inputs(ibl, orc, w):
+    """A 4096x4096/face environment (1e8 texels, 1.6 GB decoded) and, on request, 8192x8192
+    (6.4 GB: byte offsets beyond 32 bits): Lambertian 16x16/face and the two extreme GGX levels
+    of the chain, a few output texels each against the oracle."""
+    rep = w // 512
+    small = vra.synth.hdr_environment(512, seed=9).reshape(6, 512, 512, 4)
+    strip = np.repeat(np.repeat(small, rep, axis=1), rep, axis=2)
+    yy, xx = np.meshgrid(np.arange(w), np.arange(w), indexing="ij")
+    strip[..., 0] ^= ((xx + 3 * yy) & 3).astype(np.uint8)[None]        # no two neighbours alike
+    del yy, xx
+    env = orc.rgbe_decode(strip.reshape(-1, 4)).reshape(6, w, w, 4)
+    env_d = ibl.rgbe_decode(_dev(ibl, strip.reshape(-1, 4))).reshape(6, w, w, 4)
+    begin = 700
+    got = ibl.lambertian(env_d, 16).cpu().numpy()
+    want = orc.lambertian(env, 16, out_begin=begin, out_count=8)
+    _check_cube(orc, got, want, sel=slice(begin, begin + 8), label="lambertian %d" % w)
+    mips = ibl.ggx_mip_levels(w, w, 16)
+    assert mips == orc.ggx_mip_levels(w, w, 16) == {4096: 8, 8192: 9}[w]
+    got = ibl.ggx_level(env_d, 16, mips, mips).cpu().numpy()             # roughness 1: every texel of the hemisphere
+    want = orc.ggx_level(env, 16, 16, mips, mips, out_begin=begin, out_count=4)
+    _check_cube(orc, got, want, sel=slice(begin, begin + 4), tight=GGX_TIGHT, label="ggx %d level %d/%d" % (w, mips, mips))
+    half = w // 2
+    begin = 6 * half * half // 2 + half * 77 + 1000                      # the lowest roughness: a narrow lobe
+    got = ibl.ggx_level(env_d, half, 1, mips, out_begin=begin, out_count=8).cpu().numpy()
+    want = orc.ggx_level(env, half, half, 1, mips, out_begin=begin, out_count=8)
+    _check_cube(orc, got, want, sel=slice(begin, begin + 8), tight=GGX_TIGHT, label="ggx %d level 1/%d" % (w, mips))
+
+
 # ---- BRDF table ----------------------------------------------------------------------------
 
 def test_lut_matches_oracle_same_jitter(ibl, orc):
