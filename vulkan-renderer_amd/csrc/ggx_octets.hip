@@ -470,8 +470,21 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     const double seconds = wave_records * 70e-9 / 1024.0;                // ~70 ns per wave, record and pattern per SIMD
     double waves = 0.04 * seconds * 1.5e12 / (64.0 * GO_SUMS * 8.0);
     waves = fmin(fmax(waves, 131072.0), 1048576.0);
-    if (const char* e = getenv("IBL_GGX_WAVES")) waves = atof(e);        // tuning knob
     uint32_t want = (uint32_t)ceil(waves / (double)units_level);
+    // The waves in flight at one time belong to one slice and to output units from all over
+    // the octant, on every XCD; together they read all of the slice's records, each many
+    // times.  That set should sit in an XCD's 4 MiB L2 with room to spare (measured on the
+    // 2048 -> 1024 level: 4 MiB per slice 1000 ms, 2 MiB 955 ms, 1 MiB 950 ms), as long as
+    // the partial sums this costs stay below 32 GiB.
+    {
+        const double rec_total = (double)pl.n_po * ps * ps * GO_REC * sizeof(float4);
+        const double per_slice = (double)units_level * GO_UNIT * GO_SUMS * sizeof(double);
+        const double fit = ceil(rec_total / (double)(2u << 20));
+        const double afford = floor((double)(32ull << 30) / per_slice);
+        const double s = fmin(fit, afford);
+        if (s > (double)want) want = (uint32_t)s;
+    }
+    if (const char* e = getenv("IBL_GGX_WAVES")) want = (uint32_t)ceil(atof(e) / (double)units_level);   // tuning knob
     uint32_t max_slices = pl.n_po;                           // at least one patch octet per slice
     if (max_slices == 0) max_slices = 1;
     uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
