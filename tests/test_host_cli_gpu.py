@@ -83,7 +83,7 @@ def test_cube_cli_ggx_too_small_input_fails_cleanly(tmp_path):
     assert r.returncode != 0 and "at least 16x16" in r.stderr
 
 
-def test_cube_cli_generate_ggx_lut():
+def test_cube_cli_generate_ggx_lut(tmp_path):
     env = dict(os.environ, IBL_LUT_SEED="2024")
     r = subprocess.run([CUBE, "--generate-ggx-lut"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
@@ -95,6 +95,18 @@ def test_cube_cli_generate_ggx_lut():
     d = vals - ref
     assert abs(d[..., 0].mean()) < 2e-5
     assert np.sqrt((d[128, :, 0] ** 2).mean()) < 1.3e-3 and np.sqrt((d[255, :, 0] ** 2).mean()) < 1.6e-4
+    conv = np.load(os.path.join(GOLDEN, "ggx_lut_converged.npy")).astype(np.float64)
+    assert abs((vals - conv)[..., 0].mean()) < 1e-5 and abs((vals - conv)[..., 1].mean()) < 4e-7
+    # and the consumer's use of the file, descriptor.cpp:8-10, compiles to 256*256*2 floats
+    (tmp_path / "ggx_lut.inl").write_text(r.stdout)
+    (tmp_path / "use.cpp").write_text(
+        'const float pbrBRDFArray[] =\n#include "ggx_lut.inl"\n;\n'
+        'static_assert(sizeof(pbrBRDFArray) == 256 * 256 * 2 * sizeof(float), "table size");\n'
+        'int main() { return pbrBRDFArray[1] > 0.0f ? 0 : 1; }\n')
+    c = subprocess.run(["g++", "-std=c++20", "-Wall", "-Werror", "-I", str(tmp_path), str(tmp_path / "use.cpp"),
+                        "-o", str(tmp_path / "use")], capture_output=True, text=True, timeout=120)
+    assert c.returncode == 0, c.stderr
+    assert subprocess.run([str(tmp_path / "use")], timeout=30).returncode == 0
 
 
 def test_cube_cli_sampled_ggx(tmp_path, orc):
