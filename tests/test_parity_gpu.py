@@ -376,6 +376,62 @@ def test_ggx_rejects_small_and_bad_levels(ibl, orc):
     assert float(out.abs().sum()) == 0.0
 
 
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu(ibl, orc):
+    """Every entry point answers a bad argument with IBL_EINVAL and a message (the reference
+    would PANIC, util.hpp:25); nothing is launched, and the library keeps working afterwards."""
+    L, EINVAL = ibl.lib, 1
+    _, env_d = _env(ibl, orc, 16)
+    e = env_d.data_ptr()
+    out = ibl.torch.zeros((6, 8, 8, 4), dtype=ibl.torch.float32, device=ibl.device)
+    o = out.data_ptr()
+    host = np.zeros((6, 16, 16, 4), np.float32)
+    h = host.ctypes.data
+    calls = [
+        lambda: L.ibl_lambertian_dev(None, 16, 16, 8, 0, 384, o, None),
+        lambda: L.ibl_lambertian_dev(e, 16, 16, 8, 0, 384, None, None),
+        lambda: L.ibl_lambertian_dev(e, 0, 0, 8, 0, 384, o, None),
+        lambda: L.ibl_lambertian_dev(e, 16, 8, 8, 0, 384, o, None),            # faces must be square
+        lambda: L.ibl_lambertian_dev(e, 16, 16, 0, 0, 0, o, None),
+        lambda: L.ibl_lambertian_dev(e, 16, 16, 8, 380, 5, o, None),           # range past the end
+        lambda: L.ibl_lambertian_dev(e, 16, 16, 8, 0xFFFFFFFF, 2, o, None),    # begin + count wraps
+        lambda: L.ibl_lambertian_dev(e, 20000, 20000, 8, 0, 384, o, None),     # texel count leaves 31 bits
+        lambda: L.ibl_lambertian_shard_dev(e, 16, 16, 8, 0, 0, o, None),
+        lambda: L.ibl_ggx_level_dev(e, 16, 16, 8, 4, 1, 1, 0, 384, o, None),   # output faces must be square
+        lambda: L.ibl_ggx_level_dev(None, 16, 16, 8, 8, 1, 1, 0, 384, o, None),
+        lambda: L.ibl_ggx_level_shard_dev(e, 16, 16, 8, 8, 1, 1, 2, 2, o, None),
+        lambda: L.ibl_ggx_level_params(0, 5, 512, 512, None, None, None, None),
+        lambda: L.ibl_brdf_lut_dev(0, 4, 8, 1, 1, 0, 0, o, None),
+        lambda: L.ibl_brdf_lut_dev(4, 4, 0, 1, 1, 0, 16, o, None),
+        lambda: L.ibl_brdf_lut_dev(4, 4, 8, 1, 7, 0, 16, o, None),             # unknown jitter mode
+        lambda: L.ibl_brdf_lut_dev(4, 4, 8, 1, 1, 10, 7, o, None),
+        lambda: L.ibl_brdf_lut_dev(4, 4, 8, 1, 1, 0, 16, None, None),
+        lambda: L.ibl_rgbe_decode_dev(None, o, 4, None),
+        lambda: L.ibl_rgbe_encode_dev(e, None, 4, None),
+        lambda: L.ibl_downscale_dev(e, 16, 16, 3, o, None),
+        lambda: L.ibl_downscale_dev(e, 16, 16, 32, o, None),
+        lambda: L.ibl_texel_directions_dev(8, 8, 1, None, None),
+        lambda: L.ibl_env_pyramid_dev(None, 16, o, None),
+        lambda: L.ibl_ggx_level_sampled_dev(e, 16, 8, 1, 1, 0, 1.0, 0, 384, o, None),       # no samples
+        lambda: L.ibl_ggx_level_sampled_dev(e, 16, 8, 3, 2, 64, 1.0, 0, 384, o, None),
+        lambda: L.ibl_png_filter_rows_dev(None, 4, 4, o, None),
+        lambda: L.ibl_png_filter_rows_dev(e, 70000, 70000, o, None),
+        lambda: L.ibl_lambertian(None, 16, 16, 8, h),
+        lambda: L.ibl_ggx_level(h, 8, 8, 4, 4, 1, 1, h),                        # input below 16x16
+        lambda: L.ibl_brdf_lut(4, 4, 8, 1, 1, None),
+        lambda: L.ibl_downscale(h, 16, 16, 5, h),
+        lambda: L.ibl_bake_rgbe(None, 16, 1, 8, h, h),
+        lambda: L.ibl_bake_rgbe(h, 16, 3, 8, h, h),
+        lambda: L.ibl_bake_rgbe(h, 16, 1, 0, h, h),
+        lambda: L.ibl_bake_png_rows(h, 0, 1, 8, 0, 1.0, h, h),
+    ]
+    for i, call in enumerate(calls):
+        assert call() == EINVAL, (i, L.ibl_last_error())
+        assert len(L.ibl_last_error()) > 0
+    assert float(out.abs().sum()) == 0.0
+    got = ibl.lambertian(env_d, 8).cpu().numpy()                                # still in working order
+    _check_cube(orc, got, orc.lambertian(_env(ibl, orc, 16)[0], 8))
+
+
 @pytest.mark.parametrize("w", [4096, pytest.param(8192, marks=pytest.mark.skipif(
     os.environ.get("IBL_TEST_HUGE") != "1", reason="6.4 GB environment; set IBL_TEST_HUGE=1"))])
 def test_largest_inputs(ibl, orc, w):
