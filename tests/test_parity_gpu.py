@@ -376,6 +376,38 @@ def test_ggx_rejects_small_and_bad_levels(ibl, orc):
     assert float(out.abs().sum()) == 0.0
 
 
+def test_dev_calls_run_on_the_callers_stream(ibl, orc):
+    """*_dev entry points enqueue on the stream they are given and do not synchronise: a chain
+    issued on a side stream (decode -> downscale -> Lambertian / GGX -> encode -> PNG rows)
+    gives the bits of the same chain on the default stream, and the kernel timer's events
+    live on that stream too."""
+    t = ibl.torch
+    strip = vra.synth.hdr_environment(64, seed=31)
+
+    def chain():
+        env = ibl.rgbe_decode(_dev(ibl, strip.reshape(-1, 4))).reshape(6, 64, 64, 4)
+        env = ibl.downscale(env, 2)
+        lam = ibl.lambertian(env, 16)
+        ggx = ibl.ggx_level(env, 16, 1, 1)
+        rows = ibl.png_filter_rows(ibl.rgbe_encode(ggx.reshape(-1, 4)).reshape(96, 16, 4))
+        return lam, ggx, rows
+
+    want = chain()
+    t.cuda.synchronize()
+    side = t.cuda.Stream(device=ibl.device)
+    ibl.set_timing(True)
+    try:
+        with t.cuda.stream(side):
+            got = chain()
+            ms = ibl.last_kernel_ms()
+        side.synchronize()
+    finally:
+        ibl.set_timing(False)
+    assert ms > 0
+    for a, b in zip(got, want):
+        assert t.equal(a, b)
+
+
 def test_c_abi_rejects_bad_arguments_without_touching_the_gpu(ibl, orc):
     """Every entry point answers a bad argument with IBL_EINVAL and a message (the reference
     would PANIC, util.hpp:25); nothing is launched, and the library keeps working afterwards."""
