@@ -408,6 +408,32 @@ def test_dev_calls_run_on_the_callers_stream(ibl, orc):
         assert t.equal(a, b)
 
 
+def test_dev_chain_can_be_captured_in_a_hip_graph(ibl, orc):
+    """Once the library's workspaces have reached their size, the *_dev entry points only
+    enqueue kernels: a bake recorded into a HIP graph replays to the bits of the eager run."""
+    t = ibl.torch
+    strip = _dev(ibl, vra.synth.hdr_environment(64, seed=41).reshape(-1, 4))
+    full = ibl.rgbe_decode(strip).reshape(6, 64, 64, 4).contiguous()
+
+    def bake():
+        env = ibl.downscale(full, 2)
+        lam = ibl.rgbe_encode(ibl.lambertian(env, 16).reshape(-1, 4))
+        return [lam] + [ibl.rgbe_encode(ibl.ggx_level(env, 64 >> m, m, 2).reshape(-1, 4)) for m in (1, 2)]
+
+    for _ in range(2):
+        want = [x.clone() for x in bake()]
+    t.cuda.synchronize()
+    graph = t.cuda.CUDAGraph()
+    with t.cuda.graph(graph):
+        got = bake()
+    for x in got:
+        x.zero_()
+    graph.replay()
+    t.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert t.equal(a, b)
+
+
 def test_c_abi_rejects_bad_arguments_without_touching_the_gpu(ibl, orc):
     """Every entry point answers a bad argument with IBL_EINVAL and a message (the reference
     would PANIC, util.hpp:25); nothing is launched, and the library keeps working afterwards."""
