@@ -203,10 +203,86 @@ __global__ __launch_bounds__(256) void downscale_box(const float4* __restrict__ 
     out[o] = make_float4(inv * ax, inv * ay, inv * az, 0.0f);
 }
 
+// The same filter for large factors.  One thread per output texel leaves a 2048 -> 32 filter with
+// 6144 threads that each walk 4096 texels alone, far too little in flight to stream from HBM.  Here a
+// workgroup owns `tpb` neighbouring output texels of one output row: all its threads copy the rows
+// of those blocks (contiguous in memory) into LDS, a few rows at a time, and the first `tpb` threads
+// then add their own block's texels from LDS -- still one float accumulator per texel and channel,
+// in the reference's (row, column) order, so the bits do not change.  Blocks are padded to d + 1
+// texels in LDS, which spreads the adders' reads over the banks.
+constexpr uint32_t DS_THREADS = 256;
+constexpr uint32_t DS_CHUNK = 1024;          // texels staged per round (16 KiB + padding)
+#ifndef DS_TARGET_WGS
+#define DS_TARGET_WGS 1536
+#endif
+
+__global__ __launch_bounds__(DS_THREADS) void downscale_box_staged(const float4* __restrict__ env, uint32_t w,
+                                                                    uint32_t ow, uint32_t d, uint32_t log2d,
+                                                                    uint32_t tpb, uint32_t rows_per_round,
+                                                                    float4* __restrict__ out) {
+#pragma clang fp contract(off)
+    extern __shared__ float4 ds_tile[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t x0 = blockIdx.x * tpb;
+    const uint32_t n_t = min(tpb, ow - x0);              // output texels of this workgroup
+    const uint32_t oy = blockIdx.y;                      // output row within the 6-face strip
+    const uint32_t span = n_t << log2d;                  // input texels per row, contiguous
+    const float4* __restrict__ src = env + (size_t)oy * d * w + (size_t)x0 * d;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for (uint32_t yy0 = 0; yy0 < d; yy0 += rows_per_round) {
+        const uint32_t rows = min(rows_per_round, d - yy0);
+        for (uint32_t r = 0; r < rows; r++) {
+            const float4* __restrict__ row = src + (size_t)(yy0 + r) * w;
+            for (uint32_t i = tid; i < span; i += DS_THREADS) {
+                const uint32_t t = i >> log2d, xx = i & (d - 1);
+                ds_tile[(r * tpb + t) * (d + 1) + xx] = row[i];
+            }
+        }
+        __syncthreads();
+        if (tid < n_t) {
+            for (uint32_t r = 0; r < rows; r++) {
+                const float4* __restrict__ mine = ds_tile + (r * tpb + tid) * (d + 1);
+                for (uint32_t xx = 0; xx < d; xx += 8) {      // d is a multiple of 8 here
+                    float4 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] = mine[xx + k];     // eight LDS reads in flight
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { ax += v[k].x; ay += v[k].y; az += v[k].z; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < n_t) {
+        const float inv = ref_div(1.0f, (float)(d * d));
+        out[(size_t)oy * ow + x0 + tid] = make_float4(inv * ax, inv * ay, inv * az, 0.0f);
+    }
+}
+
 hipError_t downscale_launch(const float* d_env, uint32_t w, uint32_t h, uint32_t d, float* d_out, hipStream_t stream) {
     const uint32_t ow = w / d, oh = h / d;
     const uint32_t n_out = ow * oh * 6;
-    if (n_out) downscale_box<<<(n_out + 255) / 256, 256, 0, stream>>>((const float4*)d_env, w, ow, n_out, d, (float4*)d_out);
+    if (n_out == 0) return hipGetLastError();
+    if (d >= 8 && d <= DS_CHUNK && (d & (d - 1)) == 0) {    // the API only admits powers of two
+        uint32_t log2d = 0;
+        while ((1u << log2d) < d) log2d++;
+        // Few output texels per workgroup, so that there are thousands of workgroups: each one's
+        // adders walk their blocks alone, and only other workgroups can fill that time.
+        uint32_t tpb = (n_out + DS_TARGET_WGS - 1) / DS_TARGET_WGS;
+        if (tpb * d < 64) tpb = 64 / d;                  // at least 1 KiB contiguous per staged row
+        if (tpb > 64) tpb = 64;
+        if (tpb > ow) tpb = ow;
+        if (tpb * d > DS_CHUNK) tpb = DS_CHUNK / d > 0 ? DS_CHUNK / d : 1;
+        uint32_t rows = DS_CHUNK / (tpb * d);
+        if (rows < 1) rows = 1;
+        if (rows > d) rows = d;
+        const size_t lds = (size_t)rows * tpb * (d + 1) * sizeof(float4);
+        dim3 grid((ow + tpb - 1) / tpb, oh * 6);
+        downscale_box_staged<<<grid, DS_THREADS, lds, stream>>>((const float4*)d_env, w, ow, d, log2d, tpb, rows,
+                                                                (float4*)d_out);
+    } else {
+        downscale_box<<<(n_out + 255) / 256, 256, 0, stream>>>((const float4*)d_env, w, ow, n_out, d, (float4*)d_out);
+    }
     return hipGetLastError();
 }
 
