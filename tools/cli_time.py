@@ -25,9 +25,10 @@ def main():
         for _ in range(2):      # second run: warm page cache and GPU driver
             t0 = time.time()
             r = subprocess.run([cube, "--lambertian", "--ggx", "--cubemap-size", "16"] + extra + [src],
-                               capture_output=True, text=True)
+                               capture_output=True, text=True, env=dict(os.environ, IBL_CUBE_TIMING="1"))
             dt = time.time() - t0
             assert r.returncode == 0, r.stderr
+        print(r.stderr.strip())
         files = sorted(f for f in os.listdir(d) if f != "sky.png")
         print("cube %s on a %dx%d/face strip: %.2f s wall, wrote %d files (%.1f MB)"
               % (" ".join(extra) or "(quadrature)", w, w, dt, len(files),

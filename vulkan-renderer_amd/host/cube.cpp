@@ -24,6 +24,7 @@
 #include "s72_scene.hpp"
 
 #include <charconv>
+#include <chrono>
 #include <cstdlib>
 #include <filesystem>
 #include <iostream>
@@ -73,17 +74,31 @@ struct BakeOptions {
     float ggx_lod_bias = 1.0f;
 };
 
+// Stage times on stderr when IBL_CUBE_TIMING is set (diagnostics only).
+struct StageClock {
+    bool on = std::getenv("IBL_CUBE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (on) std::cerr << "[cube] " << what << ": " << std::chrono::duration<double, std::milli>(now - t).count() << " ms" << std::endl;
+        t = now;
+    }
+};
+
 // The body of the reference's main after argument parsing, cube.cpp:455-516.
 void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) {
     uint32_t w = 0, h = 0;
     std::vector<uint8_t> pixels;
     std::string err;
+    StageClock clock;
     if (!png_read_rgba8(input_path.string(), w, h, pixels, err)) PANIC("failed to load texture image! (" + err + ")");
+    clock.lap("read input PNG");
     h /= 6;
     if (w == 0 || h != w) PANIC("input must be a W x 6W strip of square cube faces");
     if (!opt.lambertian && !opt.ggx) return;
 
     check(ibl_init(-1));
+    clock.lap("open the GPU");
     const uint32_t mips = opt.ggx ? ibl_ggx_mip_levels(w, h, opt.cubemap_size) : 0;
     // The library hands back PNG scanlines (RGBE-encoded and filtered on the device); only deflate is left to do here.
     std::vector<uint8_t> lambertian(opt.lambertian ? (size_t)ibl_png_rows_bytes(opt.cubemap_size, opt.cubemap_size * 6) : 0);
@@ -92,6 +107,7 @@ void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) 
     std::vector<uint8_t> ggx(ggx_bytes);
     check(ibl_bake_png_rows(pixels.data(), w, opt.input_downscale, opt.cubemap_size, opt.ggx_samples, opt.ggx_lod_bias,
                             opt.lambertian ? lambertian.data() : nullptr, (opt.ggx && mips) ? ggx.data() : nullptr));
+    clock.lap("bake on the GPU (copies included)");
 
     if (opt.lambertian) {
         std::cout << "Integrating Lambertian: [" << std::flush;
@@ -112,6 +128,7 @@ void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) 
         if (!png_write_filtered_rows(out.string(), mw, mw * 6, ggx.data() + off, n_bytes, err)) PANIC(err);
         off += n_bytes;
     }
+    clock.lap("deflate and write the PNGs");
 }
 
 // Every environment of a scene, in the loader's numbering.

@@ -155,7 +155,11 @@ bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, 
 
     // Undo the per-row filters (one loop per filter type: this runs over every byte of a
     // strip that can hold hundreds of megabytes).
-    std::vector<unsigned char> img(stride * h);
+    // RGBA8 input (what the tool's own strips are) is unfiltered straight into the result.
+    std::vector<unsigned char> other;
+    if (color == 6) rgba.resize(stride * h);
+    else other.resize(stride * h);
+    unsigned char* const img = color == 6 ? rgba.data() : other.data();
     const size_t bpp = (size_t)channels;
     for (uint32_t y = 0; y < h; y++) {
         const unsigned char* src = &raw[(stride + 1) * y] + 1;
@@ -193,8 +197,8 @@ bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, 
         }
     }
 
-    rgba.resize((size_t)w * h * 4);
-    for (size_t i = 0; i < (size_t)w * h; i++) {
+    if (color != 6) rgba.resize((size_t)w * h * 4);
+    for (size_t i = 0; color != 6 && i < (size_t)w * h; i++) {
         const unsigned char* p = &img[i * channels];
         uint8_t* o = &rgba[i * 4];
         switch (color) {
