@@ -169,12 +169,32 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn,
     uint32_t n_po, uint32_t ps2,
     uint32_t out_w, uint32_t tw, uint32_t first_block, uint32_t block_stride, uint32_t n_oct, uint32_t oct_local,
-    uint32_t out_begin, uint32_t out_count,
+    uint32_t slices_and_order, uint32_t out_begin, uint32_t out_count,
     float cutoff, float a2m1, float cmin, float theta_acc, float core_thr,
     double* __restrict__ partial, unsigned long long* __restrict__ counts) {
+    static_assert(GO_WG == 64, "one wave per workgroup: the grid below is counted in waves");
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    const uint32_t wv = blockIdx.x * (GO_WG / 64) + (tid >> 6);      // this wave's unit among the call's
+    // Workgroups go to the 8 XCDs round-robin by their linear index, and every XCD has its own
+    // L2.  Plain order is a (units, slices) grid, units fastest: the waves in flight then belong to one
+    // slice if the call covers many units, to several if it covers few (one of 8 GPUs).  With
+    // xcd_slices the grid is laid out so that XCD k only ever works on slices k, k + 8, ...:
+    // the records an XCD's L2 has to hold are then those of one slice, however many are in
+    // flight on the chip.  The host asks for it where that matters (narrow lobes, few units).
+    // (One argument carries the slice count and, in its top bit, the order: scalar registers are
+    // short in this kernel, and one more live argument sends a third of them through spills.)
+    const uint32_t n_slices = slices_and_order & 0x7fffffffu;
+    const bool xcd_slices = (slices_and_order >> 31) != 0u;
+    const uint32_t units = (oct_local + GO_UNIT - 1) / GO_UNIT;
+    uint32_t slice, wv;                                              // wv: this wave's unit among the call's
+    if (xcd_slices) {                                                // n_slices is a multiple of 8 then
+        const uint32_t seq = blockIdx.x / 8;
+        slice = blockIdx.x % 8 + 8 * (seq / units);
+        wv = seq % units;
+    } else {                                                         // grid (units, slices)
+        slice = blockIdx.y;
+        wv = blockIdx.x;
+    }
     const uint32_t lo = wv * GO_UNIT + lane;
     if (lo >= oct_local) return;                                     // whole wave: no barrier below
     const uint32_t gidx = go_global(lo, first_block, block_stride);
@@ -238,14 +258,13 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
     // Slices interleave the patch octets (slice s owns q = s, s + S, s + 2S, ...), so
     // every slice sees every region of the sphere and the workgroups of one output
     // tile carry equal shares of its cone.
-    const uint32_t n_slices = gridDim.y;
-    const uint32_t my_count = (n_po + n_slices - 1 - blockIdx.y) / n_slices;
+    const uint32_t my_count = (n_po + n_slices - 1 - slice) / n_slices;
 
     for (uint32_t base = 0; base < my_count; base += 64) {
         // ---- candidates among the next 64 patch octets of the slice: sign patterns whose
         //      mirrored patch centre lies inside the wave's cone
         const uint32_t qi = base + lane;
-        const uint32_t q = qi * n_slices + blockIdx.y;
+        const uint32_t q = qi * n_slices + slice;
         uint32_t cmask = 0;
         if (qi < my_count) {
             const float4 c4 = pn[q];
@@ -381,8 +400,8 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
         for (int m = 0; m < 8; m++)
 #pragma unroll
             for (int k = 1; k < 4; k++)
-                partial[((size_t)blockIdx.y * GO_SUMS + (m * 3 + k - 1)) * oct_count + lo] = dacc[m][k];
-        partial[((size_t)blockIdx.y * GO_SUMS + 24) * oct_count + lo] = dacc[0][0];
+                partial[((size_t)slice * GO_SUMS + (m * 3 + k - 1)) * oct_count + lo] = dacc[m][k];
+        partial[((size_t)slice * GO_SUMS + 24) * oct_count + lo] = dacc[0][0];
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -488,6 +507,8 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     uint32_t max_slices = pl.n_po;                           // at least one patch octet per slice
     if (max_slices == 0) max_slices = 1;
     uint32_t slices = want < 1 ? 1 : (want > max_slices ? max_slices : want);
+    // a multiple of 8, so that the 8 XCDs can own equal shares of the slices (see ggx_oct_pairs)
+    if (slices >= 16) slices = (slices + 7) / 8 * 8 <= max_slices ? (slices + 7) / 8 * 8 : slices / 8 * 8;
     pl.n_slices = slices;
     // units first_block, first_block + stride, ... below units_level
     pl.out_units = first_block < units_level ? (units_level - first_block + block_stride - 1) / block_stride : 0;
@@ -515,18 +536,26 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const float theta_acc = (float)acos(fmin(1.0, fmax(-1.0, 2.0 * cut - 1.0)));
     const float a2m1 = pl.lv.alpha2 - 1.0f;
     const float core_thr = ggx_core_threshold(pl.lv.alpha2);
-    dim3 grid((pl.out_units * GO_UNIT + GO_WG - 1) / GO_WG, pl.n_slices);
+    // One wave per (unit, slice).  Slices are dealt to the XCDs (see ggx_oct_pairs) when several
+    // slices would otherwise share each L2 -- the call's units do not fill the GPU's 6144 wave
+    // slots -- and the level is in the narrow-lobe regime, where a record feeds one weight
+    // evaluation and its load latency shows (2048 -> 1024 level, an eighth of the units: 150 -> 127 ms;
+    // wide-lobe levels lose 1-3 % with it).
+    const double cone = 0.5 * (1.0 - fmax(0.0, 2.0 * (double)pl.lv.cutoff - 1.0));
+    uint32_t xcd_slices = (pl.n_slices % 8 == 0 && pl.out_units < 6144 && 8.0 * cone < 1.5) ? 1u : 0u;
+    if (const char* e = getenv("IBL_GGX_XCD_SLICES")) xcd_slices = (atoi(e) != 0 && pl.n_slices % 8 == 0) ? 1u : 0u;
+    const dim3 grid = xcd_slices ? dim3(pl.n_slices * pl.out_units) : dim3(pl.out_units, pl.n_slices);
     const uint32_t small_blocks = (pl.out_units * GO_UNIT + GO_THREADS - 1) / GO_THREADS;
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
     const uint32_t oct_count = pl.out_units * GO_UNIT;
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (d_counts)
         ggx_oct_pairs<true><<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
-            ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
+            ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, pl.n_slices | (xcd_slices << 31), out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, core_thr, d_partial, d_counts);
     else
         ggx_oct_pairs<false><<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, pl.n_po,
-            ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
+            ps2, out_w, pl.tw, first_block, block_stride, n_oct, oct_count, pl.n_slices | (xcd_slices << 31), out_begin, out_count, pl.lv.cutoff, a2m1, cmin,
             theta_acc, core_thr, d_partial, d_counts);
     if (ev1) (void)hipEventRecord(ev1, stream);
     const double* d_sums = d_partial;
