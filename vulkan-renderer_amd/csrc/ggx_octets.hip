@@ -296,10 +296,13 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
                 lane_pass |= pass ? (1u << tau) : 0u;
             }
             if (COUNT) tot_tested += (unsigned long long)__popc(lane_pass) * ps2 * 8ull;
-            uint32_t wmask = 0;
+            uint32_t wmask_v = 0;
 #pragma unroll
             for (int tau = 0; tau < 8; tau++)
-                if (__any((lane_pass >> tau) & 1u)) wmask |= 1u << tau;
+                if (__any((lane_pass >> tau) & 1u)) wmask_v |= 1u << tau;
+            // the same in every lane; said so explicitly, the pattern tests in the record loop are
+            // scalar bit tests instead of eight 64-bit lane masks that do not fit the scalar registers
+            const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_v);
             if (wmask == 0u) continue;
 
             const float4* __restrict__ rp = rec + (size_t)po * ps2 * GO_REC;   // wave-uniform
@@ -345,14 +348,20 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
                     unpack(src, r);
                     const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
                     const float s1 = a + b, s2 = a - b;
-                    if (wmask & 1u)   go_body<0, COUNT>(s1 + cc, r, thr[0], a2p, kc, n, acc, n_accepted);
-                    if (wmask & 2u)   go_body<1, COUNT>(cc - s2, r, thr[1], a2p, kc, n, acc, n_accepted);
-                    if (wmask & 4u)   go_body<2, COUNT>(s2 + cc, r, thr[2], a2p, kc, n, acc, n_accepted);
-                    if (wmask & 8u)   go_body<3, COUNT>(cc - s1, r, thr[3], a2p, kc, n, acc, n_accepted);
-                    if (wmask & 16u)  go_body<4, COUNT>(s1 - cc, r, thr[4], a2p, kc, n, acc, n_accepted);
-                    if (wmask & 32u)  go_body<5, COUNT>(-s2 - cc, r, thr[5], a2p, kc, n, acc, n_accepted);
-                    if (wmask & 64u)  go_body<6, COUNT>(s2 - cc, r, thr[6], a2p, kc, n, acc, n_accepted);
-                    if (wmask & 128u) go_body<7, COUNT>(-s1 - cc, r, thr[7], a2p, kc, n, acc, n_accepted);
+                    // The mask is re-read as an opaque scalar for every record: its eight bit tests
+                    // then stay scalar compares inside the loop.  Hoisted out of it they become
+                    // eight 64-bit lane masks, which do not fit the scalar registers, and every test
+                    // pays two v_readlane and two more vector instructions, live pattern or not.
+                    uint32_t wm = wmask;
+                    asm volatile("" : "+s"(wm));
+                    if (wm & 1u)   go_body<0, COUNT>(s1 + cc, r, thr[0], a2p, kc, n, acc, n_accepted);
+                    if (wm & 2u)   go_body<1, COUNT>(cc - s2, r, thr[1], a2p, kc, n, acc, n_accepted);
+                    if (wm & 4u)   go_body<2, COUNT>(s2 + cc, r, thr[2], a2p, kc, n, acc, n_accepted);
+                    if (wm & 8u)   go_body<3, COUNT>(cc - s1, r, thr[3], a2p, kc, n, acc, n_accepted);
+                    if (wm & 16u)  go_body<4, COUNT>(s1 - cc, r, thr[4], a2p, kc, n, acc, n_accepted);
+                    if (wm & 32u)  go_body<5, COUNT>(-s2 - cc, r, thr[5], a2p, kc, n, acc, n_accepted);
+                    if (wm & 64u)  go_body<6, COUNT>(s2 - cc, r, thr[6], a2p, kc, n, acc, n_accepted);
+                    if (wm & 128u) go_body<7, COUNT>(-s1 - cc, r, thr[7], a2p, kc, n, acc, n_accepted);
                 };
                 load(ra, e0);
                 if (wmask == 1u) {
