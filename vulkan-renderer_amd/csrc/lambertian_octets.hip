@@ -136,12 +136,19 @@ __global__ __launch_bounds__(OCT_THREADS, OCT_MIN_WAVES) void lambertian_oct_pai
     Texel c = octet_member(axis, oj, oi, 0, out_size, out_size);
     const F3 n = ref_normalize(ref_normal_from(c.face, c.x, c.y, out_size, out_size));   // cube.cpp:97
 
-    float acc[3][8];        // [channel][member]: neighbours in a pair read neighbours of the record
+    // [channel][member pair]: the two members of a pair are neighbours in the record, so one packed
+    // FMA serves both; a pattern that flips x pairs member so with so ^ 1, i.e. reads the record
+    // pair with its halves swapped (an operand modifier of the packed FMA, not an instruction).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc[3][4];
     double dacc[3][8];
 #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 3; k++) {
 #pragma unroll
-        for (int s = 0; s < 8; s++) { acc[k][s] = 0.0f; dacc[k][s] = 0.0; }
+        for (int p = 0; p < 4; p++) acc[k][p] = f32x2{0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < 8; s++) dacc[k][s] = 0.0;
+    }
     const unsigned long long full = __ballot(true);     // the wave's live lanes
 
     // Tile staging: OCT_TILE*OCT_REC = 448 float4 per tile, two per thread.
@@ -162,21 +169,27 @@ __global__ __launch_bounds__(OCT_THREADS, OCT_MIN_WAVES) void lambertian_oct_pai
         if (tile + 1 < n_tiles) fetch(tile + 1, v0, v1);
 #pragma unroll 2
         for (int e = 0; e < OCT_TILE; e++) {
-            float r[28];
+            const float4 g4 = s_rec[cur][e * OCT_REC];
+            f32x2 rp[3][4];          // radiance: [channel][member pair]
 #pragma unroll
-            for (int q = 0; q < OCT_REC; q++) {
+            for (int q = 1; q < OCT_REC; q++) {
                 const float4 t4 = s_rec[cur][e * OCT_REC + q];
-                r[4 * q] = t4.x; r[4 * q + 1] = t4.y; r[4 * q + 2] = t4.z; r[4 * q + 3] = t4.w;
+                rp[(q - 1) / 2][2 * ((q - 1) % 2)] = f32x2{t4.x, t4.y};
+                rp[(q - 1) / 2][2 * ((q - 1) % 2) + 1] = f32x2{t4.z, t4.w};
             }
-            const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
+            const float a = n.x * g4.x, b = n.y * g4.y, cc = n.z * g4.z;
             const float s1 = a + b, s2 = a - b;
             // one sign pattern: output member so pairs with input member so ^ TAU
             auto accumulate = [&](auto tau_c, float t) {
                 constexpr int TAU = decltype(tau_c)::value;
+                const f32x2 t2 = f32x2{t, t};
 #pragma unroll
                 for (int k = 0; k < 3; k++)
 #pragma unroll
-                    for (int so = 0; so < 8; so++) acc[k][so] = fmaf(t, r[4 + 8 * k + (so ^ TAU)], acc[k][so]);
+                    for (int p = 0; p < 4; p++) {
+                        const f32x2 src = rp[k][p ^ (TAU >> 1)];
+                        acc[k][p] = __builtin_elementwise_fma(t2, (TAU & 1) ? src.yx : src, acc[k][p]);
+                    }
             };
             accumulate(std::integral_constant<int, 0>{}, s1 + cc);      // (+,+,+): always positive
             // The other six patterns come in three pairs of opposite sign, (t, 7 - t): per lane
@@ -204,7 +217,11 @@ __global__ __launch_bounds__(OCT_THREADS, OCT_MIN_WAVES) void lambertian_oct_pai
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int s = 0; s < 8; s++) { dacc[k][s] += (double)acc[k][s]; acc[k][s] = 0.0f; }
+            for (int p = 0; p < 4; p++) {
+                dacc[k][2 * p] += (double)acc[k][p].x;
+                dacc[k][2 * p + 1] += (double)acc[k][p].y;
+                acc[k][p] = f32x2{0.0f, 0.0f};
+            }
         if (tile + 1 < n_tiles) {
             s_rec[cur ^ 1][tid] = v0;
             if (tid + OCT_THREADS < OCT_TILE * OCT_REC) s_rec[cur ^ 1][tid + OCT_THREADS] = v1;
