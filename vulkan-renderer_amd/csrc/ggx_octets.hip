@@ -139,11 +139,21 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
         float den = ref_ggx_denominator(us, n, -k.om_a2);
         d = core ? den : d;
     }
-    float qd = (t - k.cutoff) * __builtin_amdgcn_rcpf(d);
-    float f = (c * sq) * (qd * qd);
-    bool ok = c > thr;
-    f = ok ? f : 0.0f;
-    if (COUNT) n_acc += ok ? 1u : 0u;
+    float f;
+    if (COUNT) {            // thr: this lane's acceptance threshold on the cosine (2 if its patch test failed)
+        float qd = (t - k.cutoff) * __builtin_amdgcn_rcpf(d);
+        f = (c * sq) * (qd * qd);
+        bool ok = c > thr;
+        f = ok ? f : 0.0f;
+        n_acc += ok ? 1u : 0u;
+    } else {
+        // thr: this lane's cutoff (2 if its patch test failed).  The two acceptance tests of
+        // cube.cpp:271 are folded into output clamps: t - cutoff <= 0 outside the window and
+        // c * sqrt(t) <= 0 below the horizon both give weight 0, and the weight goes to 0
+        // continuously at either edge, so no compare and no select are needed.
+        float qd = sub_clamp01(t, thr) * __builtin_amdgcn_rcpf(d);
+        f = mul_clamp01(c, sq) * (qd * qd);
+    }
     const float fs = f * r[3];
 #pragma unroll
     for (int so = 0; so < 8; so++) {
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
                     F3 pc = { (tau & 1) ? -c4.x : c4.x, (tau & 2) ? -c4.y : c4.y, (tau & 4) ? -c4.z : c4.z };
                     pass = active && ref_cone_test(pc, n, cutoff);
                 }
-                thr[tau] = pass ? cmin : 2.0f;
+                thr[tau] = pass ? (COUNT ? cmin : cutoff) : 2.0f;
                 lane_pass |= pass ? (1u << tau) : 0u;
             }
             if (COUNT) tot_tested += (unsigned long long)__popc(lane_pass) * ps2 * 8ull;

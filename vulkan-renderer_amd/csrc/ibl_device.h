@@ -147,6 +147,11 @@ __device__ __forceinline__ float sub_clamp01(float a, float b) {
     asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ float mul_clamp01(float a, float b) {
+    float r;
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // max(0, min(1, -a - b))
 __device__ __forceinline__ float neg_sub_clamp01(float a, float b) {
     float r;
