@@ -353,10 +353,15 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
                     unpack(src, r);
                     go_body<0, COUNT>(c, r, thr[0], a2p, kc, n, acc, n_accepted);
                 };
-                auto eval_all = [&](const float4 (&src)[GO_REC]) {
+                // the same for the walk over several patterns: the three products every pattern's
+                // cosine is made of are the first use
+                auto touch3 = [&](const float4 (&src)[GO_REC], float& a, float& b, float& cc) {
+                    a = n.x * src[0].x; b = n.y * src[0].y; cc = n.z * src[0].z;
+                    asm volatile("" :: "v"(a), "v"(b), "v"(cc));
+                };
+                auto eval_all = [&](const float4 (&src)[GO_REC], float a, float b, float cc) {
                     float r[28];
                     unpack(src, r);
-                    const float a = n.x * r[0], b = n.y * r[1], cc = n.z * r[2];
                     const float s1 = a + b, s2 = a - b;
                     // The mask is re-read as an opaque scalar for every record: its eight bit tests
                     // then stay scalar compares inside the loop.  Hoisted out of it they become
@@ -389,18 +394,17 @@ __global__ __launch_bounds__(GO_WG, GO_MIN_WAVES) void ggx_oct_pairs(
                     }
                 } else {
                     for (uint32_t e = e0; e < e1; e += 2) {
-                        float keep = touch(ra);
-                        asm volatile("" :: "v"(keep));
+                        float a, b, cc;
+                        touch3(ra, a, b, cc);
                         __builtin_amdgcn_sched_barrier(0);
                         load(rb, e + 1);
                         __builtin_amdgcn_sched_barrier(0);
-                        eval_all(ra);
-                        keep = touch(rb);
-                        asm volatile("" :: "v"(keep));
+                        eval_all(ra, a, b, cc);
+                        touch3(rb, a, b, cc);
                         __builtin_amdgcn_sched_barrier(0);
                         load(ra, e + 2);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (e + 1 < e1) eval_all(rb);
+                        if (e + 1 < e1) eval_all(rb, a, b, cc);
                     }
                 }
 #pragma unroll
