@@ -1,12 +1,12 @@
 """GGX level error against the CPU oracle on a small range of output texels, for
 several settings of the exact-core threshold multiplier (env IBL_GGX_CORE).
 
-    python tools/ggx_error_probe.py in_w mips level [count] [mult ...]
+    python tests/probes/ggx_error_probe.py in_w mips level [count] [mult ...]
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

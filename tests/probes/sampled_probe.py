@@ -1,12 +1,12 @@
 """Sampled GGX mode: GPU against its CPU statement and against the quadrature, with times.
 
-    python tools/sampled_probe.py [in_w] [n_samples]
+    python tests/probes/sampled_probe.py [in_w] [n_samples]
 """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
