@@ -1,6 +1,7 @@
 """CPU-side checks of the C-ABI library: it loads, exports everything the header
 declares, does its host-only arithmetic, and refuses to run without a GPU."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -48,3 +49,15 @@ def test_no_gpu_means_loud_failure():
     assert lib.ibl_lambertian(buf, 1, 1, 1, buf) == 2
     with pytest.raises(vra.IblError):
         vra.Ibl(0)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ibl_hip.h is the C ABI: it must compile as strict C99 and as C++ with nothing but <stdint.h>."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use.c"
+    src.write_text('#include "ibl_hip.h"\nint main(void) { return IBL_OK; }\n')
+    for cmd in (["gcc", "-std=c99", "-pedantic"], ["g++", "-std=c++20", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)],
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
