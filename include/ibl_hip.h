@@ -18,9 +18,11 @@
  *     NULL = the HIP default stream) and do not synchronise.  They use a
  *     per-device workspace the library owns, so calls on one device must not
  *     overlap in time: issue them on one stream, or order streams with events.
- *   - The library is bound to one device per process (ibl_init) and keeps its
- *     state without locks, like the single-threaded tool it serves
- *     (cube.cpp:392-517): callers with several threads serialise their calls.
+ *   - The library keeps one state (workspaces, timer) per initialised device and
+ *     every call works on the state of the calling thread's current HIP device
+ *     (hipSetDevice / hipGetDevice).  The states have no locks, like the
+ *     single-threaded tool the library serves (cube.cpp:392-517): at most one
+ *     thread at a time calls in for a given device.
  *   - The functions without the suffix take HOST pointers, copy in, run, copy out
  *     and block; they are what a C++ host that used to call the reference
  *     functions calls instead.
@@ -54,10 +56,19 @@ enum {
 
 /* ---- life cycle ---------------------------------------------------------- */
 
-/* Binds the calling process to HIP device `device` (-1: the current device).
- * Fails with IBL_ENODEV when no GPU is present: there is no CPU fallback behind
- * this library. */
+/* Initialises HIP device `device` (-1: the current device) for this library and
+ * makes it the calling thread's current device.  Fails with IBL_ENODEV when no
+ * GPU is present: there is no CPU fallback behind this library.  Tuning knobs are
+ * read from the environment by the first init call and never again. */
 int ibl_init(int device);
+/* Initialises devices 0 .. n_devices-1 (0: every visible device) and leaves device 0
+ * current.  With more than one device initialised the ibl_bake_* entry points split
+ * every cube over all of them, as integrateLambertian / integrateGGX split their
+ * texel loops over the host's cores (cube.cpp:95,240); the bytes they return do not
+ * depend on the number of devices. */
+int ibl_init_all(int n_devices);
+int ibl_initialized_devices(void);
+/* Releases every initialised device. */
 int ibl_shutdown(void);
 const char* ibl_last_error(void);
 int ibl_device_count(void);
@@ -194,6 +205,15 @@ int ibl_bake_png_rows(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downsca
 int ibl_png_filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t* rows);
 
 /* ---- measurement ---------------------------------------------------------- */
+
+/* 1: every integral runs on the general kernels (any face size); 0 (default): the
+ * mirror-octet kernels wherever the face sizes allow.  Both are held to the same
+ * parity bars; the switch exists so that tests can cover both. */
+int ibl_set_kernel_mode(int general_only);
+/* Launch-shape knobs of the kernels (slice counts, grid orders; the names are the
+ * library's own, the tools under tools/ use them).  They change speed only, except
+ * the slice counts, which fix the order of the sums and with it the last bits. */
+int ibl_set_tuning(const char* name, double value);
 
 /* When enabled, every *_dev call brackets its dominant kernel with HIP events on
  * the stream it was launched on. */

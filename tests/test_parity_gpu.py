@@ -28,15 +28,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.fixture(params=["octets", "general"])
-def kernel_mode(request, monkeypatch):
+def kernel_mode(request, ibl):
     """Both implementations of the integrals: the mirror-octet kernels (default where
-    the face sizes allow) and the general kernels (forced by IBL_NO_OCTETS=1, which
-    the library reads on every call)."""
-    if request.param == "general":
-        monkeypatch.setenv("IBL_NO_OCTETS", "1")
-    else:
-        monkeypatch.delenv("IBL_NO_OCTETS", raising=False)
-    return request.param
+    the face sizes allow) and the general kernels (ibl_set_kernel_mode(1))."""
+    ibl.set_kernel_mode(request.param == "general")
+    yield request.param
+    ibl.set_kernel_mode(False)
 
 
 def _dev(ibl, arr):

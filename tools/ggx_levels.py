@@ -22,7 +22,7 @@ def main():
     mips = ibl.ggx_mip_levels(in_w, in_w, min_size)
     ibl.set_timing(True)
     for mode in ("octets", "general"):
-        os.environ["IBL_NO_OCTETS"] = "1" if mode == "general" else "0"
+        ibl.set_kernel_mode(mode == "general")
         total = 0.0
         for m in range(1, mips + 1):
             ow = in_w >> m

@@ -1,8 +1,7 @@
-"""Times lambertian_pairs for several builds of the library and several values of
-the outputs-per-thread knob, interleaved in one process (variants are extra builds
-of csrc/ under tools/variants/, see the Makefile's EXTRA/LIB variables).
+"""Times lambertian_oct_pairs for several builds of the library (tools/variants/*.so, see the
+Makefile's EXTRA/LIB variables) and several launch shapes, interleaved in one process.
 
-    python tools/tune_lambertian.py [in_w out_w]
+    python tools/tune_lamb_oct.py [in_w out_w]
 """
 import ctypes
 import glob
@@ -35,21 +34,25 @@ def main():
     libs = {"main": load(capi.LIB_PATH)}
     for p in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", "*.so"))):
         libs[os.path.basename(p)] = load(p)
-    n_out, n_in = 6 * out_w * out_w, 6 * in_w * in_w
+    n_out = 6 * out_w * out_w
     results = {}
+    ref = None
     for rnd in range(3):
         for name, lib in libs.items():
-            for p in (4, 8, 16):
-                lib.ibl_set_tuning(b"lamb_p", float(p))
-                rc = lib.ibl_lambertian_dev(env.data_ptr(), in_w, in_w, out_w, 0, n_out, out.data_ptr(), None)
-                assert rc == 0, lib.ibl_last_error()
-                ms = ctypes.c_float()
-                assert lib.ibl_last_kernel_ms(ctypes.byref(ms)) == 0
-                results.setdefault((name, p), []).append(ms.value)
-    for (name, p), v in sorted(results.items()):
-        best = min(v)
-        tf = 12.0 * n_out * n_in / (best * 1e-3) / 1e12
-        print("%-16s P=%-2d  ms min %.3f med %.3f  -> %.1f TFLOP/s (%.1f%% of 157.3)" % (name, p, best, sorted(v)[len(v) // 2], tf, 100 * tf / 157.3))
+            for run in (0, 1):
+                for affine in (0, 1):
+                    lib.ibl_set_tuning(b"lamb_oct_run", float(run))
+                    lib.ibl_set_tuning(b"lamb_oct_affine", float(affine))
+                    rc = lib.ibl_lambertian_dev(env.data_ptr(), in_w, in_w, out_w, 0, n_out, out.data_ptr(), None)
+                    assert rc == 0, lib.ibl_last_error()
+                    ms = ctypes.c_float()
+                    assert lib.ibl_last_kernel_ms(ctypes.byref(ms)) == 0
+                    results.setdefault((name, run, affine), []).append(ms.value)
+                    if ref is None:
+                        ref = out.clone()
+                    assert torch.equal(ref, out), (name, run, affine)      # same bits in every form
+    for (name, run, affine), v in sorted(results.items()):
+        print("%-20s run=%d affine=%d  ms min %.3f med %.3f" % (name, run, affine, min(v), sorted(v)[len(v) // 2]))
 
 
 if __name__ == "__main__":

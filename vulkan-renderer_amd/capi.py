@@ -27,6 +27,10 @@ _int = ctypes.c_int
 
 _SIGNATURES = {
     "ibl_init": ([_int], _int),
+    "ibl_init_all": ([_int], _int),
+    "ibl_initialized_devices": ([], _int),
+    "ibl_set_kernel_mode": ([_int], _int),
+    "ibl_set_tuning": ([ctypes.c_char_p, ctypes.c_double], _int),
     "ibl_shutdown": ([], _int),
     "ibl_last_error": ([], ctypes.c_char_p),
     "ibl_device_count": ([], _int),
@@ -274,6 +278,12 @@ class Ibl:
         return rows
 
     # -- measurement --------------------------------------------------------------------
+    def set_kernel_mode(self, general_only):
+        self._check(self.lib.ibl_set_kernel_mode(int(bool(general_only))))
+
+    def set_tuning(self, name, value):
+        self._check(self.lib.ibl_set_tuning(name.encode(), float(value)))
+
     def set_timing(self, on):
         self._check(self.lib.ibl_set_timing(int(bool(on))))
 

@@ -41,10 +41,18 @@ struct State {
     hipStream_t stream = nullptr;   // host-buffer entry points run on the default stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, counting = false, timed_valid = false;
-    Buffer a, b, pn, partial, counts, stage_in, stage_out;
+    Buffer a, b, pn, partial, counts, stage_in, stage_out, units;
     uint64_t last_counts[3] = {0, 0, 0};
     bool counts_pending = false;
-} g;
+};
+
+// One state per device.  A call works on the state of the calling thread's current HIP
+// device (hipGetDevice); S points at it from check_ready() to the end of the call.
+constexpr int MAX_DEVICES = 64;
+State g_states[MAX_DEVICES];
+thread_local State* S = nullptr;
+ibl::Tuning g_tuning;
+bool g_tuning_read = false;
 
 // Grow-only device allocation.  The old block is freed only after the device has
 // drained, because a previous asynchronous call may still be using it.
@@ -71,7 +79,13 @@ void release(Buffer& buf) {
 }
 
 int check_ready() {
-    if (!g.ready) return fail(IBL_ENODEV, "ibl_init has not succeeded in this process");
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES || !g_states[d].ready) {
+        (void)hipGetLastError();
+        S = nullptr;
+        return fail(IBL_ENODEV, "ibl_init has not succeeded for the current HIP device (%d) in this process", d);
+    }
+    S = &g_states[d];
     return IBL_OK;
 }
 
@@ -80,12 +94,71 @@ hipStream_t pick(void* stream) { return (hipStream_t)stream; }
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
 // The mirror-octet kernels need even, exactly mirror-symmetric face grids on both
-// sides.  IBL_NO_OCTETS=1 forces the general kernels (used by the tests to cover
-// both).
+// sides.  ibl_set_kernel_mode(1) (or IBL_NO_OCTETS=1 when ibl_init runs) forces the
+// general kernels; the tests use it to cover both.
 bool use_octets(uint32_t in_w, uint32_t out_w) {
-    const char* e = getenv("IBL_NO_OCTETS");
-    if (e && e[0] == '1') return false;
+    if (g_tuning.no_octets) return false;
     return ibl::cube_is_mirror_exact(in_w) && ibl::cube_is_mirror_exact(out_w);
+}
+
+void read_tuning_once() {
+    if (g_tuning_read) return;
+    g_tuning_read = true;
+    if (const char* e = getenv("IBL_NO_OCTETS")) g_tuning.no_octets = e[0] == '1';
+    if (const char* e = getenv("IBL_LAMB_P")) g_tuning.lamb_p = atoi(e);
+    if (const char* e = getenv("IBL_LAMB_OCT_SLICES")) g_tuning.lamb_oct_slices = (uint32_t)atoi(e);
+    if (const char* e = getenv("IBL_LAMB_OCT_RUN")) g_tuning.lamb_oct_run = atoi(e);
+    if (const char* e = getenv("IBL_LAMB_OCT_AFFINE")) g_tuning.lamb_oct_affine = atoi(e);
+    if (const char* e = getenv("IBL_GGX_WAVES")) g_tuning.ggx_waves = atof(e);
+    if (const char* e = getenv("IBL_GGX_XCD_SLICES")) g_tuning.ggx_xcd_slices = atoi(e);
+    if (const char* e = getenv("IBL_GGX_CORE")) g_tuning.ggx_core = (float)atof(e);
+}
+
+int init_device(int device) {
+    State& st = g_states[device];
+    if (st.ready) return IBL_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+    HIP_TRY(hipEventCreate(&st.ev0));
+    if (hipError_t e1 = hipEventCreate(&st.ev1); e1 != hipSuccess) {
+        (void)hipEventDestroy(st.ev0);
+        st.ev0 = nullptr;
+        return fail(IBL_EHIP, "hipEventCreate: %s", hipGetErrorString(e1));
+    }
+    st.device = device;
+    st.ready = true;
+    return IBL_OK;
+}
+
+void shutdown_device(int device) {
+    State& st = g_states[device];
+    if (!st.ready) return;
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    release(st.a); release(st.b); release(st.pn); release(st.partial); release(st.counts);
+    release(st.stage_in); release(st.stage_out); release(st.units);
+    if (st.ev0) (void)hipEventDestroy(st.ev0);
+    if (st.ev1) (void)hipEventDestroy(st.ev1);
+    st = State();
+}
+
+// Device list of the call's output units when the (face, y, x) range leaves part of the cube
+// out; a null list with every unit of the cube when it does not.
+int units_for_range(uint32_t unit, uint32_t tw, uint32_t out_w, uint32_t begin, uint32_t count, hipStream_t s,
+                    const uint32_t** d_list, uint32_t* n_units) {
+    const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2), total = (n_oct + unit - 1) / unit;
+    *d_list = nullptr;
+    *n_units = total;
+    if (begin == 0 && count == 6 * out_w * out_w) return IBL_OK;
+    *n_units = ibl::octet_units_in_range_count(unit, out_w, tw, begin, count);
+    if (*n_units == 0) return IBL_OK;
+    if (int rc = ensure(S->units, (size_t)total * sizeof(uint32_t))) return rc;
+    HIP_TRY(ibl::octet_units_in_range_launch(unit, out_w, tw, begin, count, (uint32_t*)S->units.ptr, s));
+    *d_list = (const uint32_t*)S->units.ptr;
+    return IBL_OK;
 }
 
 int check_cube(uint32_t w, uint32_t h, const char* what) {
@@ -103,6 +176,10 @@ int check_range(uint32_t begin, uint32_t count, uint64_t total, const char* what
 }
 
 }  // namespace
+
+namespace ibl {
+Tuning& tuning() { return g_tuning; }
+}  // namespace ibl
 
 extern "C" {
 
@@ -122,37 +199,65 @@ int ibl_init(int device) {
         return fail(IBL_ENODEV, "no HIP device visible (%s); this library has no CPU path",
                     e == hipSuccess ? "count is 0" : hipGetErrorString(e));
     }
-    if (g.ready) {
-        if (device < 0 || device == g.device) return IBL_OK;
-        ibl_shutdown();
-    }
-    if (device >= n) return fail(IBL_EINVAL, "device %d out of range (have %d)", device, n);
+    read_tuning_once();
+    if (device >= n || device >= MAX_DEVICES) return fail(IBL_EINVAL, "device %d out of range (have %d)", device, n);
     if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (int rc = init_device(device)) return rc;
     HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
-    HIP_TRY(hipEventCreate(&g.ev0));
-    if (hipError_t e1 = hipEventCreate(&g.ev1); e1 != hipSuccess) {
-        (void)hipEventDestroy(g.ev0);
-        g.ev0 = nullptr;
-        return fail(IBL_EHIP, "hipEventCreate: %s", hipGetErrorString(e1));
-    }
-    g.device = device;
-    g.ready = true;
     return IBL_OK;
 }
 
+int ibl_init_all(int n_devices) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return fail(IBL_ENODEV, "no HIP device visible (%s); this library has no CPU path",
+                    e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    }
+    read_tuning_once();
+    if (n_devices < 0 || n_devices > n || n_devices > MAX_DEVICES)
+        return fail(IBL_EINVAL, "%d devices asked for, %d visible", n_devices, n);
+    if (n_devices == 0) n_devices = n < MAX_DEVICES ? n : MAX_DEVICES;
+    for (int d = 0; d < n_devices; d++)
+        if (int rc = init_device(d)) return rc;
+    HIP_TRY(hipSetDevice(0));
+    return IBL_OK;
+}
+
+int ibl_initialized_devices(void) {
+    int n = 0;
+    for (int d = 0; d < MAX_DEVICES; d++) n += g_states[d].ready ? 1 : 0;
+    return n;
+}
+
 int ibl_shutdown(void) {
-    if (!g.ready) return IBL_OK;
-    (void)hipSetDevice(g.device);
-    (void)hipDeviceSynchronize();
-    release(g.a); release(g.b); release(g.pn); release(g.partial); release(g.counts);
-    release(g.stage_in); release(g.stage_out);
-    if (g.ev0) (void)hipEventDestroy(g.ev0);
-    if (g.ev1) (void)hipEventDestroy(g.ev1);
-    g = State();
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    bool any = false;
+    for (int d = 0; d < MAX_DEVICES; d++) { any = any || g_states[d].ready; shutdown_device(d); }
+    if (any && cur >= 0) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+    return IBL_OK;
+}
+
+int ibl_set_tuning(const char* name, double value) {
+    read_tuning_once();
+    if (!name) return fail(IBL_EINVAL, "set_tuning: null name");
+    if (!strcmp(name, "lamb_p")) g_tuning.lamb_p = (int)value;
+    else if (!strcmp(name, "lamb_oct_slices")) g_tuning.lamb_oct_slices = (uint32_t)value;
+    else if (!strcmp(name, "lamb_oct_run")) g_tuning.lamb_oct_run = (int)value;
+    else if (!strcmp(name, "lamb_oct_affine")) g_tuning.lamb_oct_affine = (int)value;
+    else if (!strcmp(name, "ggx_waves")) g_tuning.ggx_waves = value;
+    else if (!strcmp(name, "ggx_xcd_slices")) g_tuning.ggx_xcd_slices = (int)value;
+    else if (!strcmp(name, "ggx_core")) g_tuning.ggx_core = (float)value;
+    else return fail(IBL_EINVAL, "set_tuning: unknown knob %s", name);
+    return IBL_OK;
+}
+
+int ibl_set_kernel_mode(int general_only) {
+    read_tuning_once();
+    g_tuning.no_octets = general_only != 0;
     return IBL_OK;
 }
 
@@ -175,31 +280,41 @@ int ibl_ggx_level_params(uint32_t mip_level, uint32_t mip_levels, uint32_t in_w,
     return IBL_OK;
 }
 
-int ibl_set_timing(int enabled) { g.timing = enabled != 0; g.timed_valid = false; return IBL_OK; }
-int ibl_set_counting(int enabled) { g.counting = enabled != 0; return IBL_OK; }
+int ibl_set_timing(int enabled) {
+    if (int rc = check_ready()) return rc;
+    S->timing = enabled != 0;
+    S->timed_valid = false;
+    return IBL_OK;
+}
+
+int ibl_set_counting(int enabled) {
+    if (int rc = check_ready()) return rc;
+    S->counting = enabled != 0;
+    return IBL_OK;
+}
 
 int ibl_last_kernel_ms(float* ms) {
     if (int rc = check_ready()) return rc;
     if (!ms) return fail(IBL_EINVAL, "ms is null");
-    if (!g.timed_valid) return fail(IBL_EINVAL, "no timed kernel: call ibl_set_timing(1) before a *_dev call");
-    HIP_TRY(hipEventSynchronize(g.ev1));
-    HIP_TRY(hipEventElapsedTime(ms, g.ev0, g.ev1));
+    if (!S->timed_valid) return fail(IBL_EINVAL, "no timed kernel: call ibl_set_timing(1) before a *_dev call");
+    HIP_TRY(hipEventSynchronize(S->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, S->ev0, S->ev1));
     return IBL_OK;
 }
 
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
     if (int rc = check_ready()) return rc;
-    if (g.counts_pending) {
+    if (S->counts_pending) {
         unsigned long long h[3];
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(h, g.counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
-        g.last_counts[1] = h[1];
-        g.last_counts[2] = h[2];
-        g.counts_pending = false;
+        HIP_TRY(hipMemcpy(h, S->counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
+        S->last_counts[1] = h[1];
+        S->last_counts[2] = h[2];
+        S->counts_pending = false;
     }
-    if (patch_tests) *patch_tests = g.last_counts[0];
-    if (tested) *tested = g.last_counts[1];
-    if (accepted) *accepted = g.last_counts[2];
+    if (patch_tests) *patch_tests = S->last_counts[0];
+    if (tested) *tested = S->last_counts[1];
+    if (accepted) *accepted = S->last_counts[2];
     return IBL_OK;
 }
 
@@ -214,31 +329,37 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
     const uint64_t n_out = (uint64_t)out_size * out_size * 6;
     if (int rc = check_range(out_begin, out_count, n_out, "lambertian")) return rc;
     const uint32_t n_in = in_w * in_h * 6;
-    g.last_counts[0] = 0;
-    g.last_counts[1] = (uint64_t)out_count * n_in;
-    g.last_counts[2] = 0;
-    g.counts_pending = false;
-    if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
+    S->last_counts[0] = 0;
+    S->last_counts[1] = (uint64_t)out_count * n_in;
+    S->last_counts[2] = 0;
+    S->counts_pending = false;
+    if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
     hipStream_t s = pick(stream);
     if (use_octets(in_w, out_size)) {
-        // mirror-octet kernel over every output octet; texels outside the range are masked
+        // mirror-octet kernel over the 256-octet blocks that hold a texel of the range; the
+        // other members of those octets are computed and not stored
         const uint32_t n_oct = 3 * (out_size / 2) * (out_size / 2);
-        ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, out_size, n_oct);
-        if (int rc = ensure(g.a, pl.rec_bytes)) return rc;
-        if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
-        HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, 0, n_oct, out_begin, out_count, d_out, g.a.ptr,
-                                           (double*)g.partial.ptr, s, g.timing ? g.ev0 : nullptr,
-                                           g.timing ? g.ev1 : nullptr));
+        const uint32_t* d_list = nullptr;
+        uint32_t n_blocks = 0;
+        if (int rc = units_for_range(ibl::LAMBERTIAN_OCT_BLOCK, ibl::lambertian_oct_tile_edge(out_size), out_size,
+                                     out_begin, out_count, s, &d_list, &n_blocks)) return rc;
+        if (n_blocks == 0) { S->timed_valid = false; return IBL_OK; }
+        ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, n_blocks);
+        if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
+        if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+        HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, d_list, 0, n_oct, out_begin, out_count, d_out,
+                                           S->a.ptr, (double*)S->partial.ptr, s, S->timing ? S->ev0 : nullptr,
+                                           S->timing ? S->ev1 : nullptr));
     } else {
         ibl::LambertianPlan pl = ibl::lambertian_plan(n_in, out_count);
-        if (int rc = ensure(g.a, pl.prep_bytes_a)) return rc;
-        if (int rc = ensure(g.b, pl.prep_bytes_b)) return rc;
-        if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
-        HIP_TRY(ibl::lambertian_launch(pl, d_env, in_w, in_h, out_size, out_begin, out_count, d_out, g.a.ptr, g.b.ptr,
-                                       (double*)g.partial.ptr, s, g.timing ? g.ev0 : nullptr,
-                                       g.timing ? g.ev1 : nullptr));
+        if (int rc = ensure(S->a, pl.prep_bytes_a)) return rc;
+        if (int rc = ensure(S->b, pl.prep_bytes_b)) return rc;
+        if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+        HIP_TRY(ibl::lambertian_launch(pl, d_env, in_w, in_h, out_size, out_begin, out_count, d_out, S->a.ptr, S->b.ptr,
+                                       (double*)S->partial.ptr, s, S->timing ? S->ev0 : nullptr,
+                                       S->timing ? S->ev1 : nullptr));
     }
-    g.timed_valid = g.timing;
+    S->timed_valid = S->timing;
     return IBL_OK;
 }
 
@@ -261,18 +382,18 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
     const uint32_t per = (n_oct + n_shards - 1) / n_shards;
     const uint32_t begin = shard * per < n_oct ? shard * per : n_oct;
     const uint32_t count = per < n_oct - begin ? per : n_oct - begin;
-    g.last_counts[0] = 0;
-    g.last_counts[1] = (uint64_t)count * 8 * in_w * in_h * 6;
-    g.last_counts[2] = 0;
-    g.counts_pending = false;
-    if (count == 0) { g.timed_valid = false; return IBL_OK; }
-    ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, out_size, count);
-    if (int rc = ensure(g.a, pl.rec_bytes)) return rc;
-    if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
-    HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, begin, count, 0, n_out, d_out, g.a.ptr,
-                                       (double*)g.partial.ptr, pick(stream), g.timing ? g.ev0 : nullptr,
-                                       g.timing ? g.ev1 : nullptr));
-    g.timed_valid = g.timing;
+    S->last_counts[0] = 0;
+    S->last_counts[1] = (uint64_t)count * 8 * in_w * in_h * 6;
+    S->last_counts[2] = 0;
+    S->counts_pending = false;
+    if (count == 0) { S->timed_valid = false; return IBL_OK; }
+    ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, (count + ibl::LAMBERTIAN_OCT_BLOCK - 1) / ibl::LAMBERTIAN_OCT_BLOCK);
+    if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
+    if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+    HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, nullptr, begin, begin + count, 0, n_out, d_out,
+                                       S->a.ptr, (double*)S->partial.ptr, pick(stream), S->timing ? S->ev0 : nullptr,
+                                       S->timing ? S->ev1 : nullptr));
+    S->timed_valid = S->timing;
     return IBL_OK;
 }
 
@@ -296,37 +417,35 @@ int ggx_check(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, 
 }
 
 bool use_ggx_octets(uint32_t in_w, uint32_t out_w, uint32_t patch) {
-    const char* e = getenv("IBL_NO_OCTETS");
-    if (e && e[0] == '1') return false;
+    if (g_tuning.no_octets) return false;
     return ibl::ggx_octets_eligible(in_w, out_w, patch);
 }
 
 int ggx_counts_buffer(hipStream_t s, unsigned long long** d_counts) {
     *d_counts = nullptr;
-    if (!g.counting) return IBL_OK;
-    if (int rc = ensure(g.counts, 4 * sizeof(unsigned long long))) return rc;
-    *d_counts = (unsigned long long*)g.counts.ptr;
+    if (!S->counting) return IBL_OK;
+    if (int rc = ensure(S->counts, 4 * sizeof(unsigned long long))) return rc;
+    *d_counts = (unsigned long long*)S->counts.ptr;
     HIP_TRY(hipMemsetAsync(*d_counts, 0, 4 * sizeof(unsigned long long), s));
     return IBL_OK;
 }
 
-// Octet kernel over the 64-octet units first_block, first_block + block_stride, ...,
-// writing the member texels inside [out_begin, out_begin+out_count).
+// Octet kernel over the n_units 64-octet units listed in S->units, writing the member texels
+// inside [out_begin, out_begin+out_count).
 int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
-                   uint32_t first_block, uint32_t block_stride, uint32_t out_begin, uint32_t out_count, float* d_out,
-                   hipStream_t s) {
-    ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, first_block, block_stride);
-    if (pl.out_units == 0) { g.timed_valid = false; return IBL_OK; }
-    if (int rc = ensure(g.a, pl.rec_bytes)) return rc;
-    if (int rc = ensure(g.pn, pl.pn_bytes)) return rc;
-    if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
+                   uint32_t n_units, uint32_t out_begin, uint32_t out_count, float* d_out, hipStream_t s) {
+    ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, n_units);
+    if (pl.out_units == 0) { S->timed_valid = false; return IBL_OK; }
+    if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
+    if (int rc = ensure(S->pn, pl.pn_bytes)) return rc;
+    if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
     unsigned long long* d_counts = nullptr;
     if (int rc = ggx_counts_buffer(s, &d_counts)) return rc;
-    HIP_TRY(ibl::ggx_oct_launch(pl, d_env, in_w, out_w, first_block, block_stride, out_begin, out_count, d_out, g.a.ptr,
-                                g.pn.ptr, (double*)g.partial.ptr, d_counts, s, g.timing ? g.ev0 : nullptr,
-                                g.timing ? g.ev1 : nullptr));
-    g.timed_valid = g.timing;
-    g.counts_pending = g.counting;
+    HIP_TRY(ibl::ggx_oct_launch(pl, d_env, in_w, out_w, (const uint32_t*)S->units.ptr, out_begin, out_count, d_out,
+                                S->a.ptr, S->pn.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
+                                S->timing ? S->ev1 : nullptr));
+    S->timed_valid = S->timing;
+    S->counts_pending = S->counting;
     return IBL_OK;
 }
 
@@ -341,26 +460,39 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
     const uint64_t n_out = (uint64_t)out_w * out_h * 6;
     if (int rc = check_range(out_begin, out_count, n_out, "ggx")) return rc;
     const uint32_t n_patches = 6 * (in_w / patch) * (in_h / patch);
-    g.last_counts[0] = (uint64_t)out_count * n_patches;
-    g.last_counts[1] = g.last_counts[2] = 0;
-    g.counts_pending = false;
-    if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
+    S->last_counts[0] = (uint64_t)out_count * n_patches;
+    S->last_counts[1] = S->last_counts[2] = 0;
+    S->counts_pending = false;
+    if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
     hipStream_t s = pick(stream);
     if (use_ggx_octets(in_w, out_w, patch)) {
-        return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, 0, 1, out_begin, out_count, d_out, s);
+        // the 64-octet units that hold a texel of the range; the other members of their octets
+        // are computed and not stored
+        const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2), total = (n_oct + ibl::GGX_OCT_UNIT - 1) / ibl::GGX_OCT_UNIT;
+        uint32_t n_units = total;
+        if (int rc = ensure(S->units, (size_t)total * sizeof(uint32_t))) return rc;
+        if (out_begin == 0 && out_count == n_out) {
+            HIP_TRY(ibl::octet_units_strided_launch(0, 1, total, (uint32_t*)S->units.ptr, s));
+        } else {
+            const uint32_t tw = ibl::ggx_oct_tile_edge(out_w);
+            n_units = ibl::octet_units_in_range_count(ibl::GGX_OCT_UNIT, out_w, tw, out_begin, out_count);
+            HIP_TRY(ibl::octet_units_in_range_launch(ibl::GGX_OCT_UNIT, out_w, tw, out_begin, out_count,
+                                                     (uint32_t*)S->units.ptr, s));
+        }
+        return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, n_units, out_begin, out_count, d_out, s);
     }
     ibl::GgxPlan pl = ibl::ggx_plan(in_w, in_h, out_w, out_h, mip_level, mip_levels, out_count);
-    if (int rc = ensure(g.a, pl.prep_bytes_a)) return rc;
-    if (int rc = ensure(g.b, pl.prep_bytes_b)) return rc;
-    if (int rc = ensure(g.pn, pl.prep_bytes_pn)) return rc;
-    if (int rc = ensure(g.partial, pl.partial_bytes)) return rc;
+    if (int rc = ensure(S->a, pl.prep_bytes_a)) return rc;
+    if (int rc = ensure(S->b, pl.prep_bytes_b)) return rc;
+    if (int rc = ensure(S->pn, pl.prep_bytes_pn)) return rc;
+    if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
     unsigned long long* d_counts = nullptr;
     if (int rc = ggx_counts_buffer(s, &d_counts)) return rc;
-    HIP_TRY(ibl::ggx_launch(pl, d_env, in_w, in_h, out_w, out_h, out_begin, out_count, d_out, g.a.ptr, g.b.ptr,
-                            g.pn.ptr, (double*)g.partial.ptr, d_counts, s, g.timing ? g.ev0 : nullptr,
-                            g.timing ? g.ev1 : nullptr));
-    g.timed_valid = g.timing;
-    g.counts_pending = g.counting;
+    HIP_TRY(ibl::ggx_launch(pl, d_env, in_w, in_h, out_w, out_h, out_begin, out_count, d_out, S->a.ptr, S->b.ptr,
+                            S->pn.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
+                            S->timing ? S->ev1 : nullptr));
+    S->timed_valid = S->timing;
+    S->counts_pending = S->counting;
     return IBL_OK;
 }
 
@@ -384,11 +516,13 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
     const uint32_t n_units = (n_oct + 63) / 64;
     const uint32_t mine = shard < n_units ? (n_units - shard + n_shards - 1) / n_shards : 0;
-    g.last_counts[0] = (uint64_t)mine * 64 * 8 * n_patches;
-    g.last_counts[1] = g.last_counts[2] = 0;
-    g.counts_pending = false;
-    if (mine == 0) { g.timed_valid = false; return IBL_OK; }
-    return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, shard, n_shards, 0, n_out, d_out, pick(stream));
+    S->last_counts[0] = (uint64_t)mine * 64 * 8 * n_patches;
+    S->last_counts[1] = S->last_counts[2] = 0;
+    S->counts_pending = false;
+    if (mine == 0) { S->timed_valid = false; return IBL_OK; }
+    if (int rc = ensure(S->units, (size_t)mine * sizeof(uint32_t))) return rc;
+    HIP_TRY(ibl::octet_units_strided_launch(shard, n_shards, mine, (uint32_t*)S->units.ptr, pick(stream)));
+    return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, mine, 0, n_out, d_out, pick(stream));
 }
 
 int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
@@ -401,14 +535,14 @@ int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, ui
     if (jitter_mode != IBL_LUT_JITTER_COUNTER && jitter_mode != IBL_LUT_JITTER_MIDPOINT)
         return fail(IBL_EINVAL, "brdf_lut: unknown jitter mode %d", jitter_mode);
     if (int rc = check_range(cell_begin, cell_count, (uint64_t)n_rough * n_cos, "brdf_lut")) return rc;
-    g.last_counts[0] = 0;
-    g.last_counts[1] = (uint64_t)cell_count * samples_sqrt * samples_sqrt;
-    g.last_counts[2] = 0;
-    g.counts_pending = false;
+    S->last_counts[0] = 0;
+    S->last_counts[1] = (uint64_t)cell_count * samples_sqrt * samples_sqrt;
+    S->last_counts[2] = 0;
+    S->counts_pending = false;
     hipStream_t s = pick(stream);
     HIP_TRY(ibl::brdf_lut_launch(n_rough, n_cos, samples_sqrt, seed, jitter_mode, cell_begin, cell_count, d_out, s,
-                                 g.timing ? g.ev0 : nullptr, g.timing ? g.ev1 : nullptr));
-    g.timed_valid = g.timing;
+                                 S->timing ? S->ev0 : nullptr, S->timing ? S->ev1 : nullptr));
+    S->timed_valid = S->timing;
     return IBL_OK;
 }
 
@@ -475,14 +609,14 @@ int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t ou
         return fail(IBL_EINVAL, "ggx_sampled: %u samples per texel is out of range (1..2^24)", n_samples);
     if (!(lod_bias > -64.0f && lod_bias < 64.0f)) return fail(IBL_EINVAL, "ggx_sampled: lod bias out of range");
     if (int rc = check_range(out_begin, out_count, (uint64_t)out_w * out_w * 6, "ggx_sampled")) return rc;
-    g.last_counts[0] = 0;
-    g.last_counts[1] = g.last_counts[2] = (uint64_t)out_count * n_samples;
-    g.counts_pending = false;
-    if (out_count == 0) { g.timed_valid = false; return IBL_OK; }
+    S->last_counts[0] = 0;
+    S->last_counts[1] = S->last_counts[2] = (uint64_t)out_count * n_samples;
+    S->counts_pending = false;
+    if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
     HIP_TRY(ibl::ggx_sampled_launch(d_pyramid, in_w, out_w, mip_level, mip_levels, n_samples, lod_bias, out_begin,
-                                    out_count, d_out, pick(stream), g.timing ? g.ev0 : nullptr,
-                                    g.timing ? g.ev1 : nullptr));
-    g.timed_valid = g.timing;
+                                    out_count, d_out, pick(stream), S->timing ? S->ev0 : nullptr,
+                                    S->timing ? S->ev1 : nullptr));
+    S->timed_valid = S->timing;
     return IBL_OK;
 }
 
@@ -501,14 +635,14 @@ namespace {
 
 // Copies `bytes` from the host into the staging-in buffer.
 int stage_in(const void* host, size_t bytes) {
-    if (int rc = ensure(g.stage_in, bytes)) return rc;
-    HIP_TRY(hipMemcpyAsync(g.stage_in.ptr, host, bytes, hipMemcpyHostToDevice, g.stream));
+    if (int rc = ensure(S->stage_in, bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(S->stage_in.ptr, host, bytes, hipMemcpyHostToDevice, S->stream));
     return IBL_OK;
 }
 
 int stage_out(void* host, size_t bytes) {
-    HIP_TRY(hipMemcpyAsync(host, g.stage_out.ptr, bytes, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(host, S->stage_out.ptr, bytes, hipMemcpyDeviceToHost, S->stream));
+    HIP_TRY(hipStreamSynchronize(S->stream));
     return IBL_OK;
 }
 
@@ -521,9 +655,9 @@ int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_
     if (int rc = check_cube(out_size, out_size, "lambertian output")) return rc;
     const size_t in_bytes = (size_t)in_w * in_h * 6 * 16, out_bytes = (size_t)out_size * out_size * 6 * 16;
     if (int rc = stage_in(env, in_bytes)) return rc;
-    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
-    if (int rc = ibl_lambertian_dev((const float*)g.stage_in.ptr, in_w, in_h, out_size, 0, out_size * out_size * 6,
-                                    (float*)g.stage_out.ptr, nullptr)) return rc;
+    if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+    if (int rc = ibl_lambertian_dev((const float*)S->stage_in.ptr, in_w, in_h, out_size, 0, out_size * out_size * 6,
+                                    (float*)S->stage_out.ptr, nullptr)) return rc;
     return stage_out(out, out_bytes);
 }
 
@@ -535,9 +669,9 @@ int ibl_ggx_level(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_w
     if (int rc = check_cube(out_w, out_h, "ggx output")) return rc;
     const size_t in_bytes = (size_t)in_w * in_h * 6 * 16, out_bytes = (size_t)out_w * out_h * 6 * 16;
     if (int rc = stage_in(env, in_bytes)) return rc;
-    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
-    if (int rc = ibl_ggx_level_dev((const float*)g.stage_in.ptr, in_w, in_h, out_w, out_h, mip_level, mip_levels, 0,
-                                   out_w * out_h * 6, (float*)g.stage_out.ptr, nullptr)) return rc;
+    if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+    if (int rc = ibl_ggx_level_dev((const float*)S->stage_in.ptr, in_w, in_h, out_w, out_h, mip_level, mip_levels, 0,
+                                   out_w * out_h * 6, (float*)S->stage_out.ptr, nullptr)) return rc;
     return stage_out(out, out_bytes);
 }
 
@@ -549,11 +683,11 @@ int ibl_ggx_level_sampled(const float* env, uint32_t in_w, uint32_t out_w, uint3
     if (int rc = check_cube(out_w, out_w, "ggx_sampled output")) return rc;
     const size_t in_bytes = (size_t)in_w * in_w * 6 * 16, out_bytes = (size_t)out_w * out_w * 6 * 16;
     if (int rc = stage_in(env, in_bytes)) return rc;
-    if (int rc = ensure(g.a, (size_t)ibl_env_pyramid_texels(in_w) * 16)) return rc;
-    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
-    if (int rc = ibl_env_pyramid_dev((const float*)g.stage_in.ptr, in_w, (float*)g.a.ptr, nullptr)) return rc;
-    if (int rc = ibl_ggx_level_sampled_dev((const float*)g.a.ptr, in_w, out_w, mip_level, mip_levels, n_samples, lod_bias,
-                                           0, out_w * out_w * 6, (float*)g.stage_out.ptr, nullptr)) return rc;
+    if (int rc = ensure(S->a, (size_t)ibl_env_pyramid_texels(in_w) * 16)) return rc;
+    if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+    if (int rc = ibl_env_pyramid_dev((const float*)S->stage_in.ptr, in_w, (float*)S->a.ptr, nullptr)) return rc;
+    if (int rc = ibl_ggx_level_sampled_dev((const float*)S->a.ptr, in_w, out_w, mip_level, mip_levels, n_samples, lod_bias,
+                                           0, out_w * out_w * 6, (float*)S->stage_out.ptr, nullptr)) return rc;
     return stage_out(out, out_bytes);
 }
 
@@ -564,9 +698,9 @@ int ibl_brdf_lut(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64
     if (n_rough == 0 || n_cos == 0 || (uint64_t)n_rough * n_cos > (1u << 26))
         return fail(IBL_EINVAL, "brdf_lut: table %ux%u out of range", n_rough, n_cos);
     const size_t out_bytes = (size_t)n_rough * n_cos * 2 * sizeof(float);
-    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
+    if (int rc = ensure(S->stage_out, out_bytes)) return rc;
     if (int rc = ibl_brdf_lut_dev(n_rough, n_cos, samples_sqrt, seed, jitter_mode, 0, n_rough * n_cos,
-                                  (float*)g.stage_out.ptr, nullptr)) return rc;
+                                  (float*)S->stage_out.ptr, nullptr)) return rc;
     return stage_out(out_slope_bias, out_bytes);
 }
 
@@ -575,8 +709,8 @@ int ibl_rgbe_decode(const uint8_t* rgbe, float* rgba, uint32_t n) {
     if (n == 0) return IBL_OK;
     if (!rgbe || !rgba) return fail(IBL_EINVAL, "rgbe_decode: null pointer");
     if (int rc = stage_in(rgbe, (size_t)n * 4)) return rc;
-    if (int rc = ensure(g.stage_out, (size_t)n * 16)) return rc;
-    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)g.stage_in.ptr, (float*)g.stage_out.ptr, n, nullptr)) return rc;
+    if (int rc = ensure(S->stage_out, (size_t)n * 16)) return rc;
+    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)S->stage_in.ptr, (float*)S->stage_out.ptr, n, nullptr)) return rc;
     return stage_out(rgba, (size_t)n * 16);
 }
 
@@ -585,8 +719,8 @@ int ibl_rgbe_encode(const float* rgba, uint8_t* rgbe, uint32_t n) {
     if (n == 0) return IBL_OK;
     if (!rgba || !rgbe) return fail(IBL_EINVAL, "rgbe_encode: null pointer");
     if (int rc = stage_in(rgba, (size_t)n * 16)) return rc;
-    if (int rc = ensure(g.stage_out, (size_t)n * 4)) return rc;
-    if (int rc = ibl_rgbe_encode_dev((const float*)g.stage_in.ptr, (uint8_t*)g.stage_out.ptr, n, nullptr)) return rc;
+    if (int rc = ensure(S->stage_out, (size_t)n * 4)) return rc;
+    if (int rc = ibl_rgbe_encode_dev((const float*)S->stage_in.ptr, (uint8_t*)S->stage_out.ptr, n, nullptr)) return rc;
     return stage_out(rgbe, (size_t)n * 4);
 }
 
@@ -597,8 +731,8 @@ int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* o
     if (!is_pow2(d) || d > w || w % d != 0) return fail(IBL_EINVAL, "scale factor for --input-downscale should be a power of 2 >= 1");
     const size_t in_bytes = (size_t)w * h * 6 * 16, out_bytes = (size_t)(w / d) * (h / d) * 6 * 16;
     if (int rc = stage_in(env, in_bytes)) return rc;
-    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
-    if (int rc = ibl_downscale_dev((const float*)g.stage_in.ptr, w, h, d, (float*)g.stage_out.ptr, nullptr)) return rc;
+    if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+    if (int rc = ibl_downscale_dev((const float*)S->stage_in.ptr, w, h, d, (float*)S->stage_out.ptr, nullptr)) return rc;
     return stage_out(out, out_bytes);
 }
 
@@ -609,8 +743,8 @@ int ibl_png_filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t* r
     if ((uint64_t)w * h > 0x7fffffffull / 4) return fail(IBL_EINVAL, "png_filter_rows: image %ux%u too large", w, h);
     const size_t out_bytes = (size_t)ibl_png_rows_bytes(w, h);
     if (int rc = stage_in(rgba8, (size_t)w * h * 4)) return rc;
-    if (int rc = ensure(g.stage_out, out_bytes)) return rc;
-    if (int rc = ibl_png_filter_rows_dev((const uint8_t*)g.stage_in.ptr, w, h, (uint8_t*)g.stage_out.ptr, nullptr)) return rc;
+    if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+    if (int rc = ibl_png_filter_rows_dev((const uint8_t*)S->stage_in.ptr, w, h, (uint8_t*)S->stage_out.ptr, nullptr)) return rc;
     return stage_out(rows, out_bytes);
 }
 
@@ -647,8 +781,8 @@ int emit(const float* d_f, uint8_t* d_e, uint8_t* d_rows, uint32_t edge, bool pn
         src = d_rows;
         bytes = (size_t)ibl_png_rows_bytes(edge, edge * 6);
     }
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S->stream));
+    HIP_TRY(hipStreamSynchronize(S->stream));
     *written = bytes;
     return IBL_OK;
 }
@@ -672,9 +806,9 @@ int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t 
     const size_t off_full = ((size_t)n_full * 4 + 255) & ~(size_t)255;
     const size_t off_ds = off_full + (size_t)n_full * 16;
     const size_t in_total = off_ds + (input_downscale > 1 ? (size_t)n_ds * 16 : 0);
-    if (int rc = ensure(g.stage_in, in_total)) return rc;
-    char* base = (char*)g.stage_in.ptr;
-    HIP_TRY(hipMemcpyAsync(base, rgbe_in, (size_t)n_full * 4, hipMemcpyHostToDevice, g.stream));
+    if (int rc = ensure(S->stage_in, in_total)) return rc;
+    char* base = (char*)S->stage_in.ptr;
+    HIP_TRY(hipMemcpyAsync(base, rgbe_in, (size_t)n_full * 4, hipMemcpyHostToDevice, S->stream));
     float* d_full = (float*)(base + off_full);
     float* d_env = d_full;
     if (int rc = ibl_rgbe_decode_dev((const uint8_t*)base, d_full, n_full, nullptr)) return rc;
@@ -685,29 +819,29 @@ int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t 
     uint32_t mips = ggx_out ? ibl_ggx_mip_levels(w, w, cubemap_size) : 0;
     uint32_t n_max = lambertian_out ? n_lamb : 0;
     if (mips) { uint32_t n1 = (w / 2) * (w / 2) * 6; if (n1 > n_max) n_max = n1; }
-    if (n_max == 0) { HIP_TRY(hipStreamSynchronize(g.stream)); return IBL_OK; }
+    if (n_max == 0) { HIP_TRY(hipStreamSynchronize(S->stream)); return IBL_OK; }
     // Staging-out block: [float cube of the largest output][its RGBE bytes][its PNG scanlines]
     const size_t off_bytes = (size_t)n_max * 16;
     const size_t off_rows = off_bytes + (size_t)n_max * 4;
-    if (int rc = ensure(g.stage_out, off_rows + (png_rows ? (size_t)n_max * 4 + (size_t)n_max : 0))) return rc;
-    float* d_f = (float*)g.stage_out.ptr;
-    uint8_t* d_e = (uint8_t*)g.stage_out.ptr + off_bytes;
-    uint8_t* d_rows = (uint8_t*)g.stage_out.ptr + off_rows;
+    if (int rc = ensure(S->stage_out, off_rows + (png_rows ? (size_t)n_max * 4 + (size_t)n_max : 0))) return rc;
+    float* d_f = (float*)S->stage_out.ptr;
+    uint8_t* d_e = (uint8_t*)S->stage_out.ptr + off_bytes;
+    uint8_t* d_rows = (uint8_t*)S->stage_out.ptr + off_rows;
     size_t written = 0;
     if (lambertian_out) {
         if (int rc = ibl_lambertian_dev(d_env, dw, dw, cubemap_size, 0, n_lamb, d_f, nullptr)) return rc;
         if (int rc = emit(d_f, d_e, d_rows, cubemap_size, png_rows, lambertian_out, &written)) return rc;
     }
     if (mips && ggx_samples) {      // sampled mode: one pyramid of the (downscaled) environment for all levels
-        if (int rc = ensure(g.b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
-        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)g.b.ptr, nullptr)) return rc;
+        if (int rc = ensure(S->b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
+        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)S->b.ptr, nullptr)) return rc;
     }
     size_t out_off = 0;
     uint32_t mw = w / 2;
     for (uint32_t m = 1; m <= mips; m++, mw /= 2) {
         const uint32_t n_m = mw * mw * 6;
         if (ggx_samples) {
-            if (int rc = ibl_ggx_level_sampled_dev((const float*)g.b.ptr, dw, mw, m, mips, ggx_samples, lod_bias, 0, n_m,
+            if (int rc = ibl_ggx_level_sampled_dev((const float*)S->b.ptr, dw, mw, m, mips, ggx_samples, lod_bias, 0, n_m,
                                                    d_f, nullptr)) return rc;
         } else if (int rc = ibl_ggx_level_dev(d_env, dw, dw, mw, mw, m, mips, 0, n_m, d_f, nullptr)) return rc;
         if (int rc = emit(d_f, d_e, d_rows, mw, png_rows, ggx_out + out_off, &written)) return rc;

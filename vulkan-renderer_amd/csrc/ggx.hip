@@ -52,10 +52,8 @@ uint32_t ggx_mip_levels(uint32_t top_w, uint32_t top_h, uint32_t min_size) {
 float ggx_core_threshold(float alpha2) {
     // Measured against the CPU restatement: recomputing pairs with d < 2*a2 removes the
     // bias (mean error 1.5e-6 -> 1e-7 at roughness 0.2); wider cores and lobes with
-    // a2 >= 0.005 gain nothing.  IBL_GGX_CORE overrides the multiplier (diagnostics).
-    float mult = 2.0f;
-    if (const char* e = getenv("IBL_GGX_CORE")) mult = (float)atof(e);
-    return alpha2 < 0.005f ? mult * alpha2 : 0.0f;
+    // a2 >= 0.005 gain nothing.  The multiplier is a diagnostic knob (Tuning::ggx_core).
+    return alpha2 < 0.005f ? tuning().ggx_core * alpha2 : 0.0f;
 }
 
 GgxLevel ggx_level_params(uint32_t mip, uint32_t mips, uint32_t in_w, uint32_t in_h) {

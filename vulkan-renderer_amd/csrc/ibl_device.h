@@ -136,6 +136,38 @@ __host__ __device__ inline Texel octet_member(uint32_t axis, uint32_t j, uint32_
     return t;
 }
 
+// Octets are numbered tile-major: tiles of tw x tw canonical (top-left quadrant) positions,
+// tile after tile over the three axes, so that a run of consecutive numbers is a patch of
+// neighbouring directions.  hw = half the face width; tw divides hw.
+__host__ __device__ inline void octet_decode(uint32_t g, uint32_t hw, uint32_t tw, uint32_t& axis, uint32_t& oj, uint32_t& oi) {
+    const uint32_t t2 = tw * tw, tpr = hw / tw;
+    const uint32_t tile = g / t2, within = g - tile * t2;
+    const uint32_t ly = within / tw, lx = within - ly * tw;
+    axis = tile / (tpr * tpr);
+    const uint32_t trem = tile - axis * (tpr * tpr);
+    const uint32_t ty = trem / tpr, tx = trem - ty * tpr;
+    oj = ty * tw + ly;
+    oi = tx * tw + lx;
+}
+
+// Does unit u (octets u*unit .. u*unit+unit-1 of the tile-major order) hold a texel whose
+// (face, y, x) index lies in [begin, begin + count)?
+__host__ __device__ inline bool octet_unit_in_range(uint32_t u, uint32_t unit, uint32_t hw, uint32_t tw, uint32_t begin,
+                                                    uint32_t count) {
+    const uint32_t n_oct = 3 * hw * hw, w = 2 * hw;
+    for (uint32_t k = 0; k < unit; k++) {
+        const uint32_t oo = u * unit + k;
+        if (oo >= n_oct) break;
+        uint32_t axis, oj, oi;
+        octet_decode(oo, hw, tw, axis, oj, oi);
+        for (uint32_t m = 0; m < 8; m++) {
+            Texel t = octet_member(axis, oj, oi, m, w, w);
+            if ((t.face * w + t.y) * w + t.x - begin < count) return true;     // unsigned wrap handles o < begin
+        }
+    }
+    return false;
+}
+
 // v_add_f32 / v_sub_f32 with the clamp output modifier (result clamped to [0, 1]).
 __device__ __forceinline__ float add_clamp01(float a, float b) {
     float r;

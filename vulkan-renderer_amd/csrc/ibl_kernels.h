@@ -7,6 +7,21 @@
 
 namespace ibl {
 
+// Tuning and diagnostic knobs.  ibl_init reads them from the environment once
+// (IBL_NO_OCTETS, IBL_LAMB_P, IBL_LAMB_OCT_SLICES, IBL_LAMB_OCT_RUN, IBL_GGX_WAVES,
+// IBL_GGX_XCD_SLICES, IBL_GGX_CORE); no entry point looks at the environment afterwards.
+struct Tuning {
+    bool no_octets = false;        // general kernels only
+    int lamb_p = 0;                // general Lambertian kernel: output texels per thread (0: automatic)
+    uint32_t lamb_oct_slices = 0;  // octet Lambertian kernel: maximum slice count (0: 512)
+    int lamb_oct_run = -1;         // octet Lambertian kernel: 1 / 0 force / forbid the run form (-1: automatic)
+    int lamb_oct_affine = -1;      // octet Lambertian kernel: 1 / 0 force / forbid dealing slots to the XCDs (-1: automatic)
+    double ggx_waves = 0.0;        // octet GGX kernel: waves per level to aim for (0: automatic)
+    int ggx_xcd_slices = -1;       // octet GGX kernel: 1 / 0 force / forbid dealing runs to the XCDs (-1: automatic)
+    float ggx_core = 2.0f;         // multiple of alpha^2 below which the reference's own denominator is repeated
+};
+Tuning& tuning();
+
 struct LambertianPlan {
     int p;                 // output texels per thread
     uint32_t slice_len;    // input texels per slice (multiple of the LDS tile)
@@ -29,14 +44,29 @@ struct LambertianOctPlan {
     uint32_t n_oct_in;     // 3 * (in_w/2)^2
     uint32_t slice_len;    // input octets per slice
     uint32_t n_slices;
-    uint32_t reduce_groups; // > 1: the slices are summed in this many groups first
-    uint32_t out_blocks;
-    size_t partial_bytes;  // [slice (+ group)][24][oct_count] double
+    uint32_t n_runs;       // runs of 8 consecutive slices: the first stage of the summation order
+    bool run;              // a workgroup walks a whole run (large calls) or one slice (small calls)
+    uint32_t out_blocks;   // 256-octet output blocks the call covers
+    size_t partial_bytes;  // [run][24][out_blocks*256] double + (slice form) [slice][24][out_blocks*256] float
     size_t rec_bytes;      // 7 float4 per input octet
 };
-LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_size, uint32_t oct_count);
+size_t lambertian_oct_partial_bytes(const LambertianOctPlan& pl);
+uint32_t lambertian_oct_blocks_total(uint32_t out_size);
+uint32_t lambertian_oct_tile_edge(uint32_t out_size);
+constexpr uint32_t LAMBERTIAN_OCT_BLOCK = 256;   // output octets per workgroup
+// Lists of units (blocks of `unit` consecutive octets of the tile-major order, tile edge tw) for calls that
+// cover part of a cube: the units with a texel in the (face, y, x) range [begin, begin + count), ascending
+// (the host counts them, the device writes the list), or first, first + stride, ...
+uint32_t octet_units_in_range_count(uint32_t unit, uint32_t out_w, uint32_t tw, uint32_t begin, uint32_t count);
+hipError_t octet_units_in_range_launch(uint32_t unit, uint32_t out_w, uint32_t tw, uint32_t begin, uint32_t count,
+                                       uint32_t* d_list, hipStream_t stream);
+hipError_t octet_units_strided_launch(uint32_t first, uint32_t stride, uint32_t n, uint32_t* d_list, hipStream_t stream);
+LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks);
+// Output block b of the call is block d_block_list[b] of the tile-major octet order, or, without a
+// list, the 256 octets from oct_begin + 256*b; octets at or past oct_end do not exist.
 hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
-                                 uint32_t oct_begin, uint32_t oct_count, uint32_t out_begin, uint32_t out_count,
+                                 const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
+                                 uint32_t out_begin, uint32_t out_count,
                                  float* d_out, void* d_rec, double* d_partial, hipStream_t stream,
                                  hipEvent_t ev0, hipEvent_t ev1);
 
@@ -69,23 +99,24 @@ hipError_t ggx_launch(const GgxPlan& pl, const float* d_env, uint32_t in_w, uint
                       hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
 // Mirror-octet form of the GGX level (ggx_octets.hip).
+constexpr uint32_t GGX_OCT_UNIT = 64;   // output octets per wave: the unit of sharding
 struct GgxOctPlan {
     GgxLevel lv;
     uint32_t n_po;            // patch octets: 3 * (pw/2)^2
     uint32_t tw;              // edge of the output tile used for octet numbering
-    uint32_t n_slices;
-    uint32_t reduce_groups;   // > 1: the slices are summed in this many groups first
+    uint32_t n_runs;          // partial sums per output octet; a wave walks one run
+    uint32_t reduce_groups;   // > 1: the runs are summed in this many groups first
     uint32_t out_units;       // 64-octet units this call covers
-    size_t partial_bytes;     // [slice (+ group)][25][out_units*64] double
+    size_t partial_bytes;     // [group][25][out_units*64] double (two-stage sums only) + [run][25][out_units*64] float
     size_t rec_bytes;         // 7 float4 per input texel octet
     size_t pn_bytes;          // float4 per patch octet
 };
 bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
-// The call covers the 64-octet units first_block, first_block + block_stride, ... (tile-major octet order)
-GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t first_block,
-                        uint32_t block_stride);
+uint32_t ggx_oct_tile_edge(uint32_t out_w);
+// The call covers the n_units 64-octet units d_units[0], d_units[1], ... (tile-major octet order).
+GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t n_units);
 hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_w,
-                          uint32_t first_block, uint32_t block_stride, uint32_t out_begin, uint32_t out_count,
+                          const uint32_t* d_units, uint32_t out_begin, uint32_t out_count,
                           float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
                           hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 

@@ -151,8 +151,7 @@ LambertianPlan lambertian_plan(uint32_t n_in, uint32_t out_count) {
     pl.n_slices = (n_in + pl.slice_len - 1) / pl.slice_len;
     // Output texels per thread: as many (up to 4) as still leave >= ~1536 workgroups.
     int p = 4;   // 4 and 8 run at the same rate; 4 gives twice the workgroups
-    if (const char* e = getenv("IBL_LAMB_P")) {   // tuning knob, not part of the ABI
-        int v = atoi(e);
+    if (int v = tuning().lamb_p) {                // tuning knob, not part of the ABI
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) p = v;
     } else
     while (p > 1) {
