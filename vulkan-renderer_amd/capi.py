@@ -39,6 +39,7 @@ _SIGNATURES = {
                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_u32)], _int),
     "ibl_lambertian_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_lambertian_shard_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_lambertian_static_dev": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_ggx_level_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_ggx_level_shard_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_brdf_lut_dev": ([_u32, _u32, _u32, _u64, _int, _u32, _u32, _vp, _vp], _int),
@@ -171,6 +172,12 @@ class Ibl:
             out = self.torch.zeros((6, out_size, out_size, 4), dtype=self.torch.float32, device=self.device)
         self._check(self.lib.ibl_lambertian_dev(_ptr(env), w, h, out_size, out_begin, out_count, _ptr(out),
                                                 self._stream(stream)))
+        return out
+
+    def lambertian_static(self, env, out_size, out, stream=None):
+        """ibl_lambertian_static_dev: the whole cube into `out`, with no allocation anywhere in the call."""
+        w, h = self._env(env)
+        self._check(self.lib.ibl_lambertian_static_dev(_ptr(env), w, h, out_size, _ptr(out), self._stream(stream)))
         return out
 
     def lambertian_shard(self, env, out_size, shard, n_shards, out=None, stream=None):

@@ -42,6 +42,7 @@ struct State {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, counting = false, timed_valid = false;
     Buffer a, b, pn, partial, counts, stage_in, stage_out, units;
+    void* static_scratch = nullptr; // this device's copy of the file-scope scratch array (ibl_lambertian_static_dev)
     uint64_t last_counts[3] = {0, 0, 0};
     bool counts_pending = false;
 };
@@ -114,6 +115,13 @@ void read_tuning_once() {
     if (const char* e = getenv("IBL_GGX_CORE")) g_tuning.ggx_core = (float)atof(e);
 }
 
+// The 32 MiB that ibl_lambertian_static_dev works in instead of allocated workspaces.  Every
+// device the library runs on holds its own copy of this array, at its own address, until the
+// process ends; host code reaches it only through the address hipGetSymbolAddress returns
+// with that device current (State::static_scratch).
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)32 << 20;
+__device__ __align__(256) unsigned char g_static_scratch[STATIC_SCRATCH_BYTES];
+
 int init_device(int device) {
     State& st = g_states[device];
     if (st.ready) return IBL_OK;
@@ -122,12 +130,15 @@ int init_device(int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+    void* scratch = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&scratch, HIP_SYMBOL(g_static_scratch)));
     HIP_TRY(hipEventCreate(&st.ev0));
     if (hipError_t e1 = hipEventCreate(&st.ev1); e1 != hipSuccess) {
         (void)hipEventDestroy(st.ev0);
         st.ev0 = nullptr;
         return fail(IBL_EHIP, "hipEventCreate: %s", hipGetErrorString(e1));
     }
+    st.static_scratch = scratch;
     st.device = device;
     st.ready = true;
     return IBL_OK;
@@ -392,6 +403,38 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
     if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
     HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, nullptr, begin, begin + count, 0, n_out, d_out,
                                        S->a.ptr, (double*)S->partial.ptr, pick(stream), S->timing ? S->ev0 : nullptr,
+                                       S->timing ? S->ev1 : nullptr));
+    S->timed_valid = S->timing;
+    return IBL_OK;
+}
+
+int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* d_out,
+                              void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_env || !d_out) return fail(IBL_EINVAL, "lambertian_static: null pointer");
+    if (int rc = check_cube(in_w, in_h, "lambertian_static input")) return rc;
+    if (int rc = check_cube(out_size, out_size, "lambertian_static output")) return rc;
+    if (!use_octets(in_w, out_size))
+        return fail(IBL_EINVAL, "lambertian_static: face sizes %u -> %u are not served by the mirror-octet kernel "
+                    "(both must be even and exactly mirror-symmetric, as every power of two is)", in_w, out_size);
+    const uint32_t n_oct = 3 * (out_size / 2) * (out_size / 2);
+    const uint32_t n_out = out_size * out_size * 6;
+    ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, ibl::lambertian_oct_blocks_total(out_size));
+    // The run form stores an eighth of the partial sums and gives the same bits as the slice form.
+    pl.run = pl.n_slices > 1;
+    pl.partial_bytes = ibl::lambertian_oct_partial_bytes(pl);
+    const size_t rec_bytes = (pl.rec_bytes + 255) & ~(size_t)255;
+    if (rec_bytes + pl.partial_bytes > STATIC_SCRATCH_BYTES)
+        return fail(IBL_EINVAL, "lambertian_static: %u x %u/face -> %u x %u/face needs %zu bytes of scratch, the "
+                    "static array holds %zu (e.g. 512 -> 32, 256 -> 32, 128 -> 64 fit); use ibl_lambertian_dev",
+                    in_w, in_w, out_size, out_size, rec_bytes + pl.partial_bytes, STATIC_SCRATCH_BYTES);
+    S->last_counts[0] = 0;
+    S->last_counts[1] = (uint64_t)n_out * in_w * in_h * 6;
+    S->last_counts[2] = 0;
+    S->counts_pending = false;
+    unsigned char* base = (unsigned char*)S->static_scratch;
+    HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, nullptr, 0, n_oct, 0, n_out, d_out, base,
+                                       (double*)(base + rec_bytes), pick(stream), S->timing ? S->ev0 : nullptr,
                                        S->timing ? S->ev1 : nullptr));
     S->timed_valid = S->timing;
     return IBL_OK;
