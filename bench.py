@@ -168,9 +168,11 @@ class Workload:
         self.np = np
 
     def _all_reduce(self, t):
-        # gloo stages CUDA tensors through the host; with kernels that use scratch memory
-        # still in flight on the same device its copy never completes, so the rehearsal
-        # backend drains the stream first.  RCCL orders itself behind the stream.
+        # Rehearsal only (several ranks on one GPU over gloo): torch's gloo backend stages CUDA
+        # tensors through the host, and with device work still in flight on a GPU that two ranks
+        # share its all_reduce can hang, whatever the kernels are (tools/multi_proc_ggx.py MODE=nm
+        # shows it with torch matmuls alone).  Draining the stream first avoids it.  RCCL, the
+        # backend of the real path, orders itself behind the stream.
         if self.host_staged_collectives:
             self.ibl.torch.cuda.synchronize()
         self.dist.all_reduce(t)

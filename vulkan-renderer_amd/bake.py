@@ -52,7 +52,9 @@ def main(argv=None):
     def assemble(cube):
         if world > 1:
             if backend == "gloo":
-                torch.cuda.synchronize()     # gloo stages through the host; drain the stream first
+                # rehearsal only: gloo's staged all_reduce can hang with device work in flight when
+                # ranks share a GPU (tools/multi_proc_ggx.py MODE=nm), so drain the stream first
+                torch.cuda.synchronize()
             dist.all_reduce(cube)
         return cube
 
