@@ -238,6 +238,11 @@ int ibl_last_kernel_ms(float* ms);
  * (GGX counts need ibl_set_counting(1); they cost a few percent). */
 int ibl_set_counting(int enabled);
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted);
+/* Mirror-octet GGX kernel, counting on: the records the wavefronts of the last call walked,
+ * summed over wavefronts (one record = one input texel octet evaluated by 64 lanes for 64
+ * output octets under one sign pattern); 0 for other kernels.  With the kernel's instruction
+ * count per record this prices the arithmetic actually executed. */
+int ibl_last_wave_records(uint64_t* wave_records);
 
 #ifdef __cplusplus
 }

@@ -319,29 +319,89 @@ def test_ggx_512_subset_16x16_patches(ibl, orc, kernel_mode):
         _check_cube(orc, got, want, sel=slice(begin, begin + count), tight=GGX_TIGHT, label="ggx 512 level %d" % m)
 
 
-def test_ggx_2048_subset(ibl, orc):
-    """The full-bake input (2048x2048/face, 7 levels): 96 output texels of four
-    levels against the oracle (the 25M-texel environment makes more too slow on CPU)."""
-    env, env_d = _env(ibl, orc, 2048, seed=9)
+_ENV2048 = {}
+
+
+def _env2048(ibl, orc):
+    """The full-bake input (2048x2048/face, seed 9), made once per session: (host, device)."""
+    if "hdr" not in _ENV2048:
+        _ENV2048["hdr"] = _env(ibl, orc, 2048, seed=9)
+    return _ENV2048["hdr"]
+
+
+def test_ggx_2048_subset(ibl, orc, kernel_mode):
+    """The full-bake input (2048x2048/face, 7 levels): a run of output texels of every
+    level against the oracle (the 25M-texel environment makes more too slow on CPU), with
+    both kernel families."""
+    env, env_d = _env2048(ibl, orc)
     mips = orc.ggx_mip_levels(2048, 2048, 16)
     assert mips == 7
-    for m in (1, 2, 4, 7):
+    for m in range(1, mips + 1):
         ow = 2048 >> m
         n_out = 6 * ow * ow
-        count = 96
+        count = 96 if kernel_mode == "octets" else 32
+        if m in (3, 5, 6):
+            count //= 2
         begin = (n_out // 3) + 5
         got = ibl.ggx_level(env_d, ow, m, mips, out_begin=begin, out_count=count).cpu().numpy()
         want = orc.ggx_level(env, ow, ow, m, mips, out_begin=begin, out_count=count)
-        _check_cube(orc, got, want, sel=slice(begin, begin + count), tight=GGX_TIGHT, label="ggx 2048 level %d" % m)
+        _check_cube(orc, got, want, sel=slice(begin, begin + count), tight=GGX_TIGHT,
+                    label="ggx 2048 level %d (%s)" % (m, kernel_mode))
+
+
+def test_ggx_2048_full_size_properties(ibl, orc):
+    """The full-bake chain at full output size, levels 1-3 (86 % of its work and every launch
+    shape the large levels use), through size-independent properties: the sum of 8 shards
+    equals the unsharded level bit for bit, scaling the radiance by 4 scales the result
+    exactly, and a constant environment comes back as that constant."""
+    t = ibl.torch
+    env, env_d = _env2048(ibl, orc)
+    cenv, cenv_d = _env(ibl, orc, 2048, kind="const")
+    env4 = env_d * 4.0
+    for m in (1, 2, 3):
+        ow = 2048 >> m
+        full = ibl.ggx_level(env_d, ow, m, 7)
+        assert bool(t.isfinite(full).all()) and float(full[..., :3].min()) > 0.0
+        acc = t.zeros_like(full)
+        for sh in range(8):
+            one = ibl.ggx_level_shard(env_d, ow, m, 7, sh, 8)
+            assert float(((one != 0) & (acc != 0)).sum()) == 0
+            acc += one
+            del one
+        assert t.equal(acc, full)
+        del acc
+        assert t.equal(ibl.ggx_level(env4, ow, m, 7), full * 4.0)
+        c = ibl.ggx_level(cenv_d, ow, m, 7)[..., :3] / t.from_numpy(cenv[0, 0, 0, :3]).to(ibl.device)
+        assert float((c - 1.0).abs().max()) < 1e-6
+        del full, c
+
+
+def test_ggx_narrow_range_equals_full_level(ibl, orc):
+    """A range that leaves most lanes of its wavefronts without a texel to store (192 texels in
+    the middle of 512 -> 256, level 1, and a few other cuts) gives the bits of the full level:
+    what a call stores never changes how a wavefront adds."""
+    t = ibl.torch
+    env, env_d = _env(ibl, orc, 512, seed=5)
+    for m, ow in ((1, 256), (3, 64)):
+        n_out = 6 * ow * ow
+        full = ibl.ggx_level(env_d, ow, m, 5).reshape(-1, 4)
+        for begin, count in ((n_out // 2 + 37, 192), (5, 1), (n_out - 3, 3), (ow * ow - 9, 40)):
+            part = ibl.ggx_level(env_d, ow, m, 5, out_begin=begin, out_count=count).reshape(-1, 4)
+            assert t.equal(part[begin:begin + count], full[begin:begin + count]), (m, begin, count)
+            assert float(part[:begin].abs().sum()) == 0.0 and float(part[begin + count:].abs().sum()) == 0.0
+    lam_full = ibl.lambertian(env_d, 64).reshape(-1, 4)
+    for begin, count in ((6 * 64 * 64 // 2 + 11, 100), (0, 1), (64 * 64 - 2, 5)):
+        part = ibl.lambertian(env_d, 64, out_begin=begin, out_count=count).reshape(-1, 4)
+        assert t.equal(part[begin:begin + count], lam_full[begin:begin + count])
+        assert float(part[:begin].abs().sum()) == 0.0 and float(part[begin + count:].abs().sum()) == 0.0
 
 
 def test_ggx_full_size_properties(ibl, orc, kernel_mode):
-    """Config 3 at full size (levels 2-5; level 1 is covered by the subset test and
-    by the benchmark): sharded == unsharded bit for bit, constant in = constant out,
-    scaling the radiance scales the result exactly."""
+    """Config 3 at full size (levels 1, 2, 3 and 5): sharded == unsharded bit for bit,
+    constant in = constant out, scaling the radiance scales the result exactly."""
     env, env_d = _env(ibl, orc, 512, seed=5)
     cenv, cenv_d = _env(ibl, orc, 512, kind="const")
-    for m in (2, 3, 5):
+    for m in (1, 2, 3, 5):
         ow = 512 >> m
         n_out = 6 * ow * ow
         full = ibl.ggx_level(env_d, ow, m, 5)

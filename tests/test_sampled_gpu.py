@@ -44,6 +44,27 @@ def test_sampled_matches_cpu_statement(ibl, orc, w, min_size, n, bias):
         assert (got[..., 3] == 0).all()
 
 
+def test_sampled_benchmark_shapes_match_cpu_statement(ibl, orc):
+    """The shapes the benchmark configurations name: the 512x512/face chain at 1024 samples per
+    texel (a band of every level) and a level of the 2048x2048/face chain at 4096 samples
+    (64 texels), against the mode's CPU statement."""
+    for w, n, levels, cnt in ((512, 1024, (1, 2, 3, 4, 5), 96), (2048, 4096, (2,), 64)):
+        env = decode_strip(orc, vra.synth.hdr_environment(w, seed=1234))
+        pyr = ibl.env_pyramid(_dev(ibl, env))
+        want_pyr = orc.env_pyramid(env)
+        mips = ibl.ggx_mip_levels(w, w, 16)
+        for m in levels:
+            ow = w >> m
+            n_out = 6 * ow * ow
+            beg = n_out // 2 + 7
+            got = ibl.ggx_level_sampled(pyr, w, ow, m, mips, n, 1.0, out_begin=beg, out_count=cnt)
+            got = got.cpu().numpy().reshape(-1, 4)[beg:beg + cnt, :3]
+            want = orc.ggx_level_sampled(want_pyr, w, ow, m, mips, n, 1.0, beg, cnt).reshape(-1, 4)[beg:beg + cnt, :3]
+            err = np.abs(got - want) / np.abs(want)
+            print("sampled %d level %d/%d N=%d: max rel err vs CPU statement %.3g" % (w, m, mips, n, err.max()))
+            assert err.max() < STATEMENT_TOL
+
+
 def test_sampled_constant_environment(ibl, orc):
     env = decode_strip(orc, vra.synth.constant_environment(32, (1.0, 2.0, 0.5)))
     pyr = ibl.env_pyramid(_dev(ibl, env))

@@ -37,9 +37,12 @@ def main():
             total += best
             p = ibl.ggx_level_params(m, mips, env.shape[2], env.shape[1])
             flop = 30.0 * c["accepted"] + 8.0 * (c["tested"] - c["accepted"])
+            lanes = c["tested"] / (512.0 * c["wave_records"]) if c["wave_records"] else float("nan")
             print("%-8s level %d out %4d r=%.3f cutoff=%.3f tested %.3e accepted %.3e  %.3f ms  %.1f Gtested/s  %.1f TFLOP/s(alg)"
+                  "  wave-records %.3e (lanes in use %.3f, %.1f ns each per SIMD)"
                   % (mode, m, ow, p["roughness"], p["cutoff"], c["tested"], c["accepted"], best,
-                     c["tested"] / best / 1e6, flop / best / 1e9))
+                     c["tested"] / best / 1e6, flop / best / 1e9, c["wave_records"], lanes,
+                     best * 1e6 * 1024 / max(c["wave_records"], 1)))
         print("%-8s chain kernel total %.3f ms" % (mode, total))
 
 

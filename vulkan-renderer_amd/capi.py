@@ -68,6 +68,7 @@ _SIGNATURES = {
     "ibl_last_kernel_ms": ([ctypes.POINTER(ctypes.c_float)], _int),
     "ibl_set_counting": ([_int], _int),
     "ibl_last_counts": ([ctypes.POINTER(_u64)] * 3, _int),
+    "ibl_last_wave_records": ([ctypes.POINTER(_u64)], _int),
 }
 
 
@@ -305,7 +306,9 @@ class Ibl:
     def last_counts(self):
         a, b, c = _u64(), _u64(), _u64()
         self._check(self.lib.ibl_last_counts(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        return dict(patch_tests=a.value, tested=b.value, accepted=c.value)
+        d = _u64()
+        self._check(self.lib.ibl_last_wave_records(ctypes.byref(d)))
+        return dict(patch_tests=a.value, tested=b.value, accepted=c.value, wave_records=d.value)
 
     # -- host-buffer entry points ---------------------------------------------------------
     @staticmethod

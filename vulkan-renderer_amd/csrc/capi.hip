@@ -43,7 +43,7 @@ struct State {
     bool timing = false, counting = false, timed_valid = false;
     Buffer a, b, pn, partial, counts, stage_in, stage_out, units;
     void* static_scratch = nullptr; // this device's copy of the file-scope scratch array (ibl_lambertian_static_dev)
-    uint64_t last_counts[3] = {0, 0, 0};
+    uint64_t last_counts[4] = {0, 0, 0, 0};   // patch tests, texel tests, accepted, wave-records
     bool counts_pending = false;
 };
 
@@ -316,16 +316,23 @@ int ibl_last_kernel_ms(float* ms) {
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
     if (int rc = check_ready()) return rc;
     if (S->counts_pending) {
-        unsigned long long h[3];
+        unsigned long long h[4];
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, S->counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
         S->last_counts[1] = h[1];
         S->last_counts[2] = h[2];
+        S->last_counts[3] = h[3];
         S->counts_pending = false;
     }
     if (patch_tests) *patch_tests = S->last_counts[0];
     if (tested) *tested = S->last_counts[1];
     if (accepted) *accepted = S->last_counts[2];
+    return IBL_OK;
+}
+
+int ibl_last_wave_records(uint64_t* wave_records) {
+    if (int rc = ibl_last_counts(nullptr, nullptr, nullptr)) return rc;
+    if (wave_records) *wave_records = S->last_counts[3];
     return IBL_OK;
 }
 
@@ -341,6 +348,7 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
     if (int rc = check_range(out_begin, out_count, n_out, "lambertian")) return rc;
     const uint32_t n_in = in_w * in_h * 6;
     S->last_counts[0] = 0;
+    S->last_counts[3] = 0;
     S->last_counts[1] = (uint64_t)out_count * n_in;
     S->last_counts[2] = 0;
     S->counts_pending = false;
@@ -394,6 +402,7 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
     const uint32_t begin = shard * per < n_oct ? shard * per : n_oct;
     const uint32_t count = per < n_oct - begin ? per : n_oct - begin;
     S->last_counts[0] = 0;
+    S->last_counts[3] = 0;
     S->last_counts[1] = (uint64_t)count * 8 * in_w * in_h * 6;
     S->last_counts[2] = 0;
     S->counts_pending = false;
@@ -429,6 +438,7 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
                     "static array holds %zu (e.g. 512 -> 32, 256 -> 32, 128 -> 64 fit); use ibl_lambertian_dev",
                     in_w, in_w, out_size, out_size, rec_bytes + pl.partial_bytes, STATIC_SCRATCH_BYTES);
     S->last_counts[0] = 0;
+    S->last_counts[3] = 0;
     S->last_counts[1] = (uint64_t)n_out * in_w * in_h * 6;
     S->last_counts[2] = 0;
     S->counts_pending = false;
@@ -504,6 +514,7 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
     if (int rc = check_range(out_begin, out_count, n_out, "ggx")) return rc;
     const uint32_t n_patches = 6 * (in_w / patch) * (in_h / patch);
     S->last_counts[0] = (uint64_t)out_count * n_patches;
+    S->last_counts[3] = 0;
     S->last_counts[1] = S->last_counts[2] = 0;
     S->counts_pending = false;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
@@ -560,6 +571,7 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
     const uint32_t n_units = (n_oct + 63) / 64;
     const uint32_t mine = shard < n_units ? (n_units - shard + n_shards - 1) / n_shards : 0;
     S->last_counts[0] = (uint64_t)mine * 64 * 8 * n_patches;
+    S->last_counts[3] = 0;
     S->last_counts[1] = S->last_counts[2] = 0;
     S->counts_pending = false;
     if (mine == 0) { S->timed_valid = false; return IBL_OK; }
@@ -579,6 +591,7 @@ int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, ui
         return fail(IBL_EINVAL, "brdf_lut: unknown jitter mode %d", jitter_mode);
     if (int rc = check_range(cell_begin, cell_count, (uint64_t)n_rough * n_cos, "brdf_lut")) return rc;
     S->last_counts[0] = 0;
+    S->last_counts[3] = 0;
     S->last_counts[1] = (uint64_t)cell_count * samples_sqrt * samples_sqrt;
     S->last_counts[2] = 0;
     S->counts_pending = false;
@@ -653,6 +666,7 @@ int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t ou
     if (!(lod_bias > -64.0f && lod_bias < 64.0f)) return fail(IBL_EINVAL, "ggx_sampled: lod bias out of range");
     if (int rc = check_range(out_begin, out_count, (uint64_t)out_w * out_w * 6, "ggx_sampled")) return rc;
     S->last_counts[0] = 0;
+    S->last_counts[3] = 0;
     S->last_counts[1] = S->last_counts[2] = (uint64_t)out_count * n_samples;
     S->counts_pending = false;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
 #pragma unroll
     for (int k = 0; k < GO_SUMS; k++) s_run[k][lane] = 0.0f;
     uint32_t n_accepted = 0;
-    unsigned long long tot_tested = 0, tot_accepted = 0;
+    unsigned long long tot_tested = 0, tot_accepted = 0, tot_walked = 0;
 
     // Three levels of sums, all in a fixed order: FP32 chunks of at most 256 terms in registers;
     // the run's FP32 running sums of its chunks (a few dozen) in LDS, indexed by output member;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
                     };
                     if (core_near) walk(std::true_type{});
                     else walk(std::false_type{});
-                    if (COUNT) { tot_accepted += (unsigned long long)n_accepted * 8ull; n_accepted = 0; }
+                    if (COUNT) { tot_accepted += (unsigned long long)n_accepted * 8ull; n_accepted = 0; tot_walked += ps2; }
                 }
             }
         }
@@ -455,7 +455,11 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
             tot_tested += __shfl_xor(tot_tested, off);
             tot_accepted += __shfl_xor(tot_accepted, off);
         }
-        if (lane == 0) { atomicAdd(&counts[1], tot_tested); atomicAdd(&counts[2], tot_accepted); }
+        if (lane == 0) {
+            atomicAdd(&counts[1], tot_tested);
+            atomicAdd(&counts[2], tot_accepted);
+            atomicAdd(&counts[3], tot_walked);       // records this wave evaluated (64 lanes each)
+        }
     }
 }
 
