@@ -123,6 +123,35 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
                             uint32_t mip_level, uint32_t mip_levels,
                             uint32_t shard, uint32_t n_shards, float* d_out, void* stream);
 
+/* ---- shards: the exchange step between GPUs ---------------------------------- */
+
+/* The reference splits the texel loops of integrateLambertian / integrateGGX over the host's
+ * cores (cube.cpp:95,240) and every thread stores into the one shared cube.  Between GPUs the
+ * store becomes an exchange: every GPU packs the texels of its shard, one all-gather moves the
+ * packed shards (each texel crosses the links once), and every GPU (or only the one that
+ * encodes) scatters them into its cube.  The functions below describe the partition that
+ * ibl_lambertian_shard_dev (kind IBL_SHARD_LAMBERTIAN; mip arguments ignored) and
+ * ibl_ggx_level_shard_dev (IBL_SHARD_GGX) use for a cube of face edge out_w computed from an
+ * input of face edge in_w; it depends on which kernel family serves those sizes. */
+enum { IBL_SHARD_LAMBERTIAN = 0, IBL_SHARD_GGX = 1 };
+/* Texel slots of one packed shard, the same for every shard (short shards are padded); 0 for
+ * invalid arguments.  Host arithmetic only. */
+uint32_t ibl_shard_texels(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                          uint32_t n_shards);
+/* The (face, y, x) texel index of every slot of shard `shard`, 0xffffffff for padding.
+ * Host arithmetic only (needs no GPU). */
+int ibl_shard_indices(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                      uint32_t shard, uint32_t n_shards, uint32_t* indices);
+/* d_packed[slot] = d_cube[texel of the slot] (zero for padding); texel_bytes is 16 (RGBA
+ * float32) or 4 (RGBE). */
+int ibl_shard_pack_dev(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                       uint32_t shard, uint32_t n_shards, uint32_t texel_bytes, const void* d_cube, void* d_packed,
+                       void* stream);
+/* The inverse for all shards at once: d_packed_all holds the n_shards packed shards back to
+ * back (what an all-gather delivers); every texel of the cube is written. */
+int ibl_shard_unpack_dev(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                         uint32_t n_shards, uint32_t texel_bytes, const void* d_packed_all, void* d_cube, void* stream);
+
 /* generateGGXLUT's cell loop, cube.cpp:346-385 (no printing): d_out is
  * [n_rough][n_cos][2] float32 (slope, bias). */
 int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
@@ -195,6 +224,13 @@ int ibl_rgbe_decode(const uint8_t* rgbe, float* rgba, uint32_t n);
 int ibl_rgbe_encode(const float* rgba, uint8_t* rgbe, uint32_t n);
 int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* out);
 
+/* Progress of the ibl_bake_* calls: fn(cube, user) is called, from a thread of the library,
+ * each time a cube's bytes have arrived in the caller's buffer -- cube 0 is the Lambertian
+ * cube, cube m > 0 GGX level m, in that order -- where the reference draws its progress bars
+ * (cube.cpp:76-92,131-132,220-236,311-312).  NULL switches it off. */
+typedef void (*ibl_progress_fn)(int cube, void* user);
+int ibl_set_progress(ibl_progress_fn fn, void* user);
+
 /* The whole bake of main, cube.cpp:457-514, with the input resident on the device
  * across all steps: RGBE strip in, RGBE strips out.  rgbe_in is w x 6w x 4 bytes.
  * lambertian_out (may be NULL) receives cubemap_size^2*6*4 bytes; ggx_out (may be
@@ -203,6 +239,10 @@ int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* o
  * (cube.cpp:473-474,513). */
 int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
                   uint8_t* lambertian_out, uint8_t* ggx_out);
+/* With several devices initialised (ibl_init_all) the three bake calls run one host thread per
+ * device: every device decodes the strip, computes its shard of every cube (the partition of
+ * the *_shard_dev entry points), packs its texels and hands them to the host, which assembles
+ * the cubes.  The bytes returned do not depend on the number of devices. */
 
 /* The same bake with the GGX levels computed by the sampled mode above (ggx_samples > 0;
  * 0 selects the quadrature, i.e. ibl_bake_rgbe).  No counterpart in the reference. */
@@ -238,11 +278,14 @@ int ibl_last_kernel_ms(float* ms);
  * (GGX counts need ibl_set_counting(1); they cost a few percent). */
 int ibl_set_counting(int enabled);
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted);
-/* Mirror-octet GGX kernel, counting on: the records the wavefronts of the last call walked,
- * summed over wavefronts (one record = one input texel octet evaluated by 64 lanes for 64
- * output octets under one sign pattern); 0 for other kernels.  With the kernel's instruction
- * count per record this prices the arithmetic actually executed. */
-int ibl_last_wave_records(uint64_t* wave_records);
+/* Mirror-octet kernels, counting on: what the wavefronts of the last Lambertian or GGX call
+ * executed.  wave_records: records walked, summed over wavefronts (a record is one input texel
+ * octet, evaluated by the 64 lanes of a wavefront for 64 output octets); wave_patterns: sign
+ * patterns evaluated for them (the Lambertian kernel evaluates 4 to 7 per record, skipping the
+ * ones a whole wavefront agrees are negative; the GGX kernel walks a record once per pattern).
+ * With the kernels' instruction counts per record and per pattern this prices the arithmetic
+ * actually executed.  0 for the general kernels. */
+int ibl_last_wave_work(uint64_t* wave_records, uint64_t* wave_patterns);
 
 #ifdef __cplusplus
 }

@@ -681,3 +681,51 @@ def test_bake_png_rows_is_bake_rgbe_filtered(ibl, orc):
     only_lam, none = ibl.bake_png_rows(strip, cubemap_size=16, ggx=False)
     np.testing.assert_array_equal(only_lam, lam_rows)
     assert none == []
+
+
+def test_bake_on_several_shards_returns_the_same_bytes(ibl, orc):
+    """The path ibl_bake_* takes when several devices are initialised (one host thread per
+    device: shard kernels, encode, pack, copy, scatter on the host), rehearsed on one GPU by
+    letting it play 1, 3 and 8 shards in turn: same bytes as the one-device bake, for pixels
+    and for PNG scanlines, quadrature and sampled GGX, and the progress callback names every
+    cube once, in order."""
+    import ctypes
+    strip = vra.synth.hdr_environment(64, seed=23)
+    want_lam, want_levels = ibl.bake_rgbe(strip, input_downscale=2, cubemap_size=16)
+    want_rows = ibl.bake_png_rows(strip, input_downscale=2, cubemap_size=16)
+    want_s = ibl.bake_rgbe(strip, cubemap_size=16, ggx_samples=64)
+    seen = []
+    cb = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)(lambda cube, user: seen.append(cube))
+    try:
+        for shards in (1, 3, 8):
+            ibl.set_tuning("bake_rehearse_shards", shards if shards > 1 else 0)
+            if shards == 1:
+                continue
+            assert ibl.lib.ibl_set_progress(ctypes.cast(cb, ctypes.c_void_p), None) == 0
+            del seen[:]
+            lam, levels = ibl.bake_rgbe(strip, input_downscale=2, cubemap_size=16)
+            assert seen == [0, 1, 2]
+            np.testing.assert_array_equal(lam, want_lam)
+            for a, b in zip(levels, want_levels):
+                np.testing.assert_array_equal(a, b)
+            del seen[:]
+            lam_rows, level_rows = ibl.bake_png_rows(strip, input_downscale=2, cubemap_size=16)
+            assert seen == [0, 1, 2]
+            np.testing.assert_array_equal(lam_rows, want_rows[0])
+            for a, b in zip(level_rows, want_rows[1]):
+                np.testing.assert_array_equal(a, b)
+            lam_s, levels_s = ibl.bake_rgbe(strip, cubemap_size=16, ggx_samples=64)
+            np.testing.assert_array_equal(lam_s, want_s[0])
+            for a, b in zip(levels_s, want_s[1]):
+                np.testing.assert_array_equal(a, b)
+            only, none = ibl.bake_rgbe(strip, cubemap_size=16, ggx=False)
+            assert none == [] and only.shape == (96, 16, 4)
+    finally:
+        ibl.set_tuning("bake_rehearse_shards", 0)
+        ibl.lib.ibl_set_progress(None, None)
+    # the one-device bake reports progress too
+    ibl.lib.ibl_set_progress(ctypes.cast(cb, ctypes.c_void_p), None)
+    del seen[:]
+    ibl.bake_rgbe(strip, input_downscale=2, cubemap_size=16)
+    ibl.lib.ibl_set_progress(None, None)
+    assert seen == [0, 1, 2]

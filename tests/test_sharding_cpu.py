@@ -1,4 +1,4 @@
-"""CPU tests of the multi-GPU host logic: range partition and the one all-gather
+"""CPU tests of the multi-GPU host logic: the partitions and the one all-gather per cube
 that assembles a sharded bake, run as two gloo ranks.  The per-rank compute is
 stood in for by the oracle (the HIP path needs a GPU); what is under test is the
 partition/gather code that bench.py runs between the HIP calls."""
@@ -32,17 +32,30 @@ def test_shard_range_covers_everything_once():
             assert (seen == 1).all()
 
 
-def test_weighted_ranges_balance_cost():
-    # GGX levels: cost per output row falls with the level; ranges must be contiguous and balanced
-    costs = [8.0] * 100 + [1.0] * 400 + [0.25] * 800
-    for world in (1, 2, 4, 8):
-        ranges = sharding.weighted_shard_ranges(costs, world)
-        assert len(ranges) == world
-        assert ranges[0][0] == 0 and sum(c for _, c in ranges) == len(costs)
-        for (b0, c0), (b1, _) in zip(ranges[:-1], ranges[1:]):
-            assert b0 + c0 == b1
-        totals = [sum(costs[b:b + c]) for b, c in ranges]
-        assert max(totals) <= sum(costs) / world + max(costs) + 1e-9
+def test_shard_partitions_cover_every_texel_once():
+    """The library's own partitions (host arithmetic of libibl_hip.so, no GPU needed): contiguous
+    octet ranges for Lambertian, strided 64-octet units for GGX, plain ranges where the general
+    kernels serve the sizes."""
+    from vulkan_renderer_amd import capi
+    for kind, in_w, out_w, mip, mips in ((capi.SHARD_LAMBERTIAN, 64, 32, 1, 1), (capi.SHARD_GGX, 64, 32, 1, 2),
+                                         (capi.SHARD_GGX, 512, 256, 1, 5), (capi.SHARD_LAMBERTIAN, 30, 5, 1, 1),
+                                         (capi.SHARD_GGX, 100, 50, 1, 2), (capi.SHARD_LAMBERTIAN, 1024, 128, 1, 1),
+                                         (capi.SHARD_GGX, 2048, 16, 7, 7)):
+        for n in (1, 2, 3, 8):
+            per_shard = [capi.shard_indices(kind, in_w, out_w, mip, mips, r, n) for r in range(n)]
+            assert len({len(a) for a in per_shard}) == 1          # equal packed sizes: one all-gather
+            cat = np.concatenate(per_shard)
+            valid = cat[cat != 0xffffffff]
+            assert len(valid) == 6 * out_w * out_w and len(np.unique(valid)) == len(valid)
+            # mirror images stay together wherever the octet kernels serve the sizes
+            if in_w % 2 == 0 and out_w % 2 == 0 and (out_w & (out_w - 1)) == 0 and (in_w & (in_w - 1)) == 0:
+                for a in per_shard:
+                    v = a[a != 0xffffffff]
+                    assert len(v) % 8 == 0
+    lib = capi.load_library()
+    assert lib.ibl_shard_texels(7, 64, 32, 1, 1, 2) == 0 and b"kind" in lib.ibl_last_error()
+    assert lib.ibl_shard_texels(capi.SHARD_GGX, 8, 4, 1, 1, 2) == 0
+    assert lib.ibl_shard_indices(capi.SHARD_GGX, 64, 32, 1, 2, 2, 2, None) != 0
 
 
 def _free_port():
@@ -77,6 +90,21 @@ def _worker(rank, world, port, n_units_list, ret):
         full = torch.from_numpy(mine.reshape(-1, 4).copy())
         sharding.all_gather_ranges(dist, full, n_out, rank, world)
         ok = ok and np.array_equal(full.numpy(), oracle.ggx_level(env, out_w, out_w, 1, 1).reshape(-1, 4))
+    # the collective the Lambertian / GGX product path uses: the library's shard of the cube
+    # packed, one all-gather, every shard scattered into place
+    from vulkan_renderer_amd import capi
+    for kind, out_w, make in ((capi.SHARD_LAMBERTIAN, 8, lambda: oracle.lambertian(env, 8)),
+                              (capi.SHARD_GGX, 8, lambda: oracle.ggx_level(env, 8, 8, 1, 1))):
+        want = torch.from_numpy(make().reshape(-1, 4).copy())
+        idx = [capi.shard_indices(kind, 16, out_w, 1, 1, r, world) for r in range(world)]
+        mine = torch.zeros_like(want)                       # this rank holds only its own shard's texels
+        own = idx[rank][idx[rank] != 0xffffffff].astype(np.int64)
+        mine[own] = want[own]
+        packed = sharding.pack_by_indices(mine, idx[rank])
+        every = sharding.all_gather_packed(dist, packed, world)
+        assert every.shape[0] == world * len(idx[rank])
+        full = sharding.unpack_by_indices(every, np.concatenate(idx), torch.full_like(want, -1.0))
+        ok = ok and bool(torch.equal(full, want))
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

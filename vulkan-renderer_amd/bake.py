@@ -4,9 +4,9 @@
         -m vulkan_renderer_amd.bake [--lambertian] [--ggx] [--cubemap-size S] [--input-downscale D] file.png
 
 Same flags, defaults and output files as bin/cube (src/utilities/cube.cpp:392-517 in the
-reference).  Every rank decodes the strip, bakes its shard of every output cube into a
-zero-filled cube, one all-reduce per cube (a sum of disjoint supports, hence exact)
-assembles it, and rank 0 encodes to RGBE and writes X.lambertian.png / X.ggx<m>.png.
+reference).  Every rank decodes the strip and bakes its shard of every output cube; the
+ranks pack their shards' texels, one all-gather per cube moves them and a scatter puts them
+in place; rank 0 encodes to RGBE and writes X.lambertian.png / X.ggx<m>.png.
 A texel's value does not depend on the number of ranks, so the files hold the same
 pixels as a single-GPU run of bin/cube.  Run without a launcher it is a one-GPU bake.
 """
@@ -34,7 +34,7 @@ def main(argv=None):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from . import capi, pngio
+    from . import capi, pngio, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -49,14 +49,9 @@ def main(argv=None):
         dist.init_process_group(backend, rank=rank, world_size=world)
     ibl = capi.Ibl(local_rank)
 
-    def assemble(cube):
-        if world > 1:
-            if backend == "gloo":
-                # rehearsal only: gloo's staged all_reduce can hang with device work in flight when
-                # ranks share a GPU (tools/multi_proc_ggx.py MODE=nm), so drain the stream first
-                torch.cuda.synchronize()
-            dist.all_reduce(cube)
-        return cube
+    def assemble(kind, in_w, cube, mip=1, mips=1):
+        # over gloo on one shared GPU (rehearsal) the shards travel through host tensors: see sharding.gather_cube
+        return sharding.gather_cube(dist, ibl, kind, in_w, cube, mip, mips, rank, world, via_host=backend == "gloo")
 
     strip = pngio.read_rgba8(args.file)
     h6, w = strip.shape[0], strip.shape[1]
@@ -77,14 +72,14 @@ def main(argv=None):
         size = args.cubemap_size
         out = torch.zeros((6, size, size, 4), dtype=torch.float32, device=ibl.device)
         ibl.lambertian_shard(env, size, rank, world, out=out)
-        write(".lambertian.png", assemble(out), size)
+        write(".lambertian.png", assemble(capi.SHARD_LAMBERTIAN, int(env.shape[2]), out), size)
     if args.ggx:                                                             # cube.cpp:512-514
         mips = ibl.ggx_mip_levels(w, w, args.cubemap_size)                   # from the pre-downscale size, :473-474
         for m in range(1, mips + 1):
             size = w >> m
             out = torch.zeros((6, size, size, 4), dtype=torch.float32, device=ibl.device)
             ibl.ggx_level_shard(env, size, m, mips, rank, world, out=out)
-            write(".ggx%d.png" % m, assemble(out), size)
+            write(".ggx%d.png" % m, assemble(capi.SHARD_GGX, int(env.shape[2]), out, m, mips), size)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

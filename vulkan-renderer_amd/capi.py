@@ -17,6 +17,8 @@ _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libibl_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "ibl_hip.h")
 
+SHARD_LAMBERTIAN = 0
+SHARD_GGX = 1
 LUT_JITTER_COUNTER = 1
 LUT_JITTER_MIDPOINT = 2
 
@@ -42,6 +44,10 @@ _SIGNATURES = {
     "ibl_lambertian_static_dev": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_ggx_level_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_ggx_level_shard_dev": ([_vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp], _int),
+    "ibl_shard_texels": ([_int, _u32, _u32, _u32, _u32, _u32], _u32),
+    "ibl_shard_indices": ([_int, _u32, _u32, _u32, _u32, _u32, _u32, _vp], _int),
+    "ibl_shard_pack_dev": ([_int, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp], _int),
+    "ibl_shard_unpack_dev": ([_int, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp], _int),
     "ibl_brdf_lut_dev": ([_u32, _u32, _u32, _u64, _int, _u32, _u32, _vp, _vp], _int),
     "ibl_rgbe_decode_dev": ([_vp, _vp, _u32, _vp], _int),
     "ibl_rgbe_encode_dev": ([_vp, _vp, _u32, _vp], _int),
@@ -58,6 +64,7 @@ _SIGNATURES = {
     "ibl_rgbe_decode": ([_vp, _vp, _u32], _int),
     "ibl_rgbe_encode": ([_vp, _vp, _u32], _int),
     "ibl_downscale": ([_vp, _u32, _u32, _u32, _vp], _int),
+    "ibl_set_progress": ([_vp, _vp], _int),
     "ibl_bake_rgbe": ([_vp, _u32, _u32, _u32, _vp, _vp], _int),
     "ibl_bake_rgbe_sampled": ([_vp, _u32, _u32, _u32, _u32, ctypes.c_float, _vp, _vp], _int),
     "ibl_png_rows_bytes": ([_u32, _u32], _u64),
@@ -68,7 +75,7 @@ _SIGNATURES = {
     "ibl_last_kernel_ms": ([ctypes.POINTER(ctypes.c_float)], _int),
     "ibl_set_counting": ([_int], _int),
     "ibl_last_counts": ([ctypes.POINTER(_u64)] * 3, _int),
-    "ibl_last_wave_records": ([ctypes.POINTER(_u64)], _int),
+    "ibl_last_wave_work": ([ctypes.POINTER(_u64)] * 2, _int),
 }
 
 
@@ -81,6 +88,18 @@ class IblError(RuntimeError):
 def build():
     """Compile libibl_hip.so for gfx950 with hipcc (works without a GPU)."""
     subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+
+
+def shard_indices(kind, in_w, out_w, mip, mips, shard, n_shards):
+    """Texel index of every slot of a shard (host arithmetic in the library; needs no GPU):
+    uint32 array, 0xffffffff for padding."""
+    lib = load_library()
+    per = lib.ibl_shard_texels(kind, in_w, out_w, mip, mips, n_shards)
+    idx = np.empty(per, np.uint32)
+    rc = lib.ibl_shard_indices(kind, in_w, out_w, mip, mips, shard, n_shards, idx.ctypes.data)
+    if rc != 0:
+        raise IblError(rc, lib.ibl_last_error().decode())
+    return idx
 
 
 def exported_symbols():
@@ -209,6 +228,27 @@ class Ibl:
                                                      _ptr(out), self._stream(stream)))
         return out
 
+    # -- shards: the exchange step between GPUs ----------------------------------------------
+    def shard_texels(self, kind, in_w, out_w, mip=1, mips=1, n_shards=1):
+        return int(self.lib.ibl_shard_texels(kind, in_w, out_w, mip, mips, n_shards))
+
+    def shard_pack(self, kind, in_w, cube, mip, mips, shard, n_shards, stream=None):
+        """The shard's texels of `cube` ((6, W, W, 4) float32 or uint8) as a packed (slots, 4) tensor."""
+        out_w = int(cube.shape[1])
+        per = self.shard_texels(kind, in_w, out_w, mip, mips, n_shards)
+        packed = self.torch.empty((per, 4), dtype=cube.dtype, device=self.device)
+        self._check(self.lib.ibl_shard_pack_dev(kind, in_w, out_w, mip, mips, shard, n_shards, cube.element_size() * 4,
+                                                _ptr(cube), _ptr(packed), self._stream(stream)))
+        return packed
+
+    def shard_unpack(self, kind, in_w, packed_all, cube, mip, mips, n_shards, stream=None):
+        """Scatters the n_shards packed shards (back to back) into `cube`."""
+        out_w = int(cube.shape[1])
+        assert packed_all.is_contiguous() and packed_all.dtype == cube.dtype
+        self._check(self.lib.ibl_shard_unpack_dev(kind, in_w, out_w, mip, mips, n_shards, cube.element_size() * 4,
+                                                  _ptr(packed_all), _ptr(cube), self._stream(stream)))
+        return cube
+
     def brdf_lut(self, n_rough=256, n_cos=256, samples_sqrt=32, seed=0, mode=LUT_JITTER_COUNTER,
                  cell_begin=0, cell_count=None, out=None, stream=None):
         n = n_rough * n_cos
@@ -306,9 +346,9 @@ class Ibl:
     def last_counts(self):
         a, b, c = _u64(), _u64(), _u64()
         self._check(self.lib.ibl_last_counts(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        d = _u64()
-        self._check(self.lib.ibl_last_wave_records(ctypes.byref(d)))
-        return dict(patch_tests=a.value, tested=b.value, accepted=c.value, wave_records=d.value)
+        d, e = _u64(), _u64()
+        self._check(self.lib.ibl_last_wave_work(ctypes.byref(d), ctypes.byref(e)))
+        return dict(patch_tests=a.value, tested=b.value, accepted=c.value, wave_records=d.value, wave_patterns=e.value)
 
     # -- host-buffer entry points ---------------------------------------------------------
     @staticmethod

@@ -12,6 +12,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -43,8 +49,8 @@ struct State {
     bool timing = false, counting = false, timed_valid = false;
     Buffer a, b, pn, partial, counts, stage_in, stage_out, units;
     void* static_scratch = nullptr; // this device's copy of the file-scope scratch array (ibl_lambertian_static_dev)
-    uint64_t last_counts[4] = {0, 0, 0, 0};   // patch tests, texel tests, accepted, wave-records
-    bool counts_pending = false;
+    uint64_t last_counts[5] = {0, 0, 0, 0, 0};   // patch tests, texel tests, accepted, wave-records, wave-patterns
+    int counts_pending = 0;          // 1: a GGX call's counters wait on the device, 2: a Lambertian call's
 };
 
 // One state per device.  A call works on the state of the calling thread's current HIP
@@ -156,6 +162,16 @@ void shutdown_device(int device) {
     st = State();
 }
 
+// The device counters of the counting kernel variants, zeroed on the stream (null when counting is off).
+int counts_buffer(hipStream_t s, unsigned long long** d_counts) {
+    *d_counts = nullptr;
+    if (!S->counting) return IBL_OK;
+    if (int rc = ensure(S->counts, 8 * sizeof(unsigned long long))) return rc;
+    *d_counts = (unsigned long long*)S->counts.ptr;
+    HIP_TRY(hipMemsetAsync(*d_counts, 0, 8 * sizeof(unsigned long long), s));
+    return IBL_OK;
+}
+
 // Device list of the call's output units when the (face, y, x) range leaves part of the cube
 // out; a null list with every unit of the cube when it does not.
 int units_for_range(uint32_t unit, uint32_t tw, uint32_t out_w, uint32_t begin, uint32_t count, hipStream_t s,
@@ -262,6 +278,7 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "ggx_waves")) g_tuning.ggx_waves = value;
     else if (!strcmp(name, "ggx_xcd_slices")) g_tuning.ggx_xcd_slices = (int)value;
     else if (!strcmp(name, "ggx_core")) g_tuning.ggx_core = (float)value;
+    else if (!strcmp(name, "bake_rehearse_shards")) g_tuning.bake_rehearse_shards = (int)value;
     else return fail(IBL_EINVAL, "set_tuning: unknown knob %s", name);
     return IBL_OK;
 }
@@ -316,13 +333,13 @@ int ibl_last_kernel_ms(float* ms) {
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
     if (int rc = check_ready()) return rc;
     if (S->counts_pending) {
-        unsigned long long h[4];
+        unsigned long long h[5];
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, S->counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
-        S->last_counts[1] = h[1];
-        S->last_counts[2] = h[2];
+        if (S->counts_pending == 1) { S->last_counts[1] = h[1]; S->last_counts[2] = h[2]; }   // GGX: texel tests
         S->last_counts[3] = h[3];
-        S->counts_pending = false;
+        S->last_counts[4] = h[4];
+        S->counts_pending = 0;
     }
     if (patch_tests) *patch_tests = S->last_counts[0];
     if (tested) *tested = S->last_counts[1];
@@ -330,9 +347,10 @@ int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted)
     return IBL_OK;
 }
 
-int ibl_last_wave_records(uint64_t* wave_records) {
+int ibl_last_wave_work(uint64_t* wave_records, uint64_t* wave_patterns) {
     if (int rc = ibl_last_counts(nullptr, nullptr, nullptr)) return rc;
     if (wave_records) *wave_records = S->last_counts[3];
+    if (wave_patterns) *wave_patterns = S->last_counts[4];
     return IBL_OK;
 }
 
@@ -348,10 +366,10 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
     if (int rc = check_range(out_begin, out_count, n_out, "lambertian")) return rc;
     const uint32_t n_in = in_w * in_h * 6;
     S->last_counts[0] = 0;
-    S->last_counts[3] = 0;
+    S->last_counts[3] = S->last_counts[4] = 0;
     S->last_counts[1] = (uint64_t)out_count * n_in;
     S->last_counts[2] = 0;
-    S->counts_pending = false;
+    S->counts_pending = 0;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
     hipStream_t s = pick(stream);
     if (use_octets(in_w, out_size)) {
@@ -366,9 +384,12 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
         ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, n_blocks);
         if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
         if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+        unsigned long long* d_counts = nullptr;
+        if (int rc = counts_buffer(s, &d_counts)) return rc;
         HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, d_list, 0, n_oct, out_begin, out_count, d_out,
-                                           S->a.ptr, (double*)S->partial.ptr, s, S->timing ? S->ev0 : nullptr,
+                                           S->a.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
                                            S->timing ? S->ev1 : nullptr));
+        S->counts_pending = S->counting ? 2 : 0;
     } else {
         ibl::LambertianPlan pl = ibl::lambertian_plan(n_in, out_count);
         if (int rc = ensure(S->a, pl.prep_bytes_a)) return rc;
@@ -402,17 +423,20 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
     const uint32_t begin = shard * per < n_oct ? shard * per : n_oct;
     const uint32_t count = per < n_oct - begin ? per : n_oct - begin;
     S->last_counts[0] = 0;
-    S->last_counts[3] = 0;
+    S->last_counts[3] = S->last_counts[4] = 0;
     S->last_counts[1] = (uint64_t)count * 8 * in_w * in_h * 6;
     S->last_counts[2] = 0;
-    S->counts_pending = false;
+    S->counts_pending = 0;
     if (count == 0) { S->timed_valid = false; return IBL_OK; }
     ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, (count + ibl::LAMBERTIAN_OCT_BLOCK - 1) / ibl::LAMBERTIAN_OCT_BLOCK);
     if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
     if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+    unsigned long long* d_counts = nullptr;
+    if (int rc = counts_buffer(pick(stream), &d_counts)) return rc;
     HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, nullptr, begin, begin + count, 0, n_out, d_out,
-                                       S->a.ptr, (double*)S->partial.ptr, pick(stream), S->timing ? S->ev0 : nullptr,
-                                       S->timing ? S->ev1 : nullptr));
+                                       S->a.ptr, (double*)S->partial.ptr, d_counts, pick(stream),
+                                       S->timing ? S->ev0 : nullptr, S->timing ? S->ev1 : nullptr));
+    S->counts_pending = S->counting ? 2 : 0;
     S->timed_valid = S->timing;
     return IBL_OK;
 }
@@ -438,13 +462,13 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
                     "static array holds %zu (e.g. 512 -> 32, 256 -> 32, 128 -> 64 fit); use ibl_lambertian_dev",
                     in_w, in_w, out_size, out_size, rec_bytes + pl.partial_bytes, STATIC_SCRATCH_BYTES);
     S->last_counts[0] = 0;
-    S->last_counts[3] = 0;
+    S->last_counts[3] = S->last_counts[4] = 0;
     S->last_counts[1] = (uint64_t)n_out * in_w * in_h * 6;
     S->last_counts[2] = 0;
-    S->counts_pending = false;
+    S->counts_pending = 0;
     unsigned char* base = (unsigned char*)S->static_scratch;
     HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, nullptr, 0, n_oct, 0, n_out, d_out, base,
-                                       (double*)(base + rec_bytes), pick(stream), S->timing ? S->ev0 : nullptr,
+                                       (double*)(base + rec_bytes), nullptr, pick(stream), S->timing ? S->ev0 : nullptr,
                                        S->timing ? S->ev1 : nullptr));
     S->timed_valid = S->timing;
     return IBL_OK;
@@ -474,15 +498,6 @@ bool use_ggx_octets(uint32_t in_w, uint32_t out_w, uint32_t patch) {
     return ibl::ggx_octets_eligible(in_w, out_w, patch);
 }
 
-int ggx_counts_buffer(hipStream_t s, unsigned long long** d_counts) {
-    *d_counts = nullptr;
-    if (!S->counting) return IBL_OK;
-    if (int rc = ensure(S->counts, 4 * sizeof(unsigned long long))) return rc;
-    *d_counts = (unsigned long long*)S->counts.ptr;
-    HIP_TRY(hipMemsetAsync(*d_counts, 0, 4 * sizeof(unsigned long long), s));
-    return IBL_OK;
-}
-
 // Octet kernel over the n_units 64-octet units listed in S->units, writing the member texels
 // inside [out_begin, out_begin+out_count).
 int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
@@ -493,12 +508,12 @@ int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t m
     if (int rc = ensure(S->pn, pl.pn_bytes)) return rc;
     if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
     unsigned long long* d_counts = nullptr;
-    if (int rc = ggx_counts_buffer(s, &d_counts)) return rc;
+    if (int rc = counts_buffer(s, &d_counts)) return rc;
     HIP_TRY(ibl::ggx_oct_launch(pl, d_env, in_w, out_w, (const uint32_t*)S->units.ptr, out_begin, out_count, d_out,
                                 S->a.ptr, S->pn.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
                                 S->timing ? S->ev1 : nullptr));
     S->timed_valid = S->timing;
-    S->counts_pending = S->counting;
+    S->counts_pending = S->counting ? 1 : 0;
     return IBL_OK;
 }
 
@@ -514,9 +529,9 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
     if (int rc = check_range(out_begin, out_count, n_out, "ggx")) return rc;
     const uint32_t n_patches = 6 * (in_w / patch) * (in_h / patch);
     S->last_counts[0] = (uint64_t)out_count * n_patches;
-    S->last_counts[3] = 0;
+    S->last_counts[3] = S->last_counts[4] = 0;
     S->last_counts[1] = S->last_counts[2] = 0;
-    S->counts_pending = false;
+    S->counts_pending = 0;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
     hipStream_t s = pick(stream);
     if (use_ggx_octets(in_w, out_w, patch)) {
@@ -541,12 +556,12 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
     if (int rc = ensure(S->pn, pl.prep_bytes_pn)) return rc;
     if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
     unsigned long long* d_counts = nullptr;
-    if (int rc = ggx_counts_buffer(s, &d_counts)) return rc;
+    if (int rc = counts_buffer(s, &d_counts)) return rc;
     HIP_TRY(ibl::ggx_launch(pl, d_env, in_w, in_h, out_w, out_h, out_begin, out_count, d_out, S->a.ptr, S->b.ptr,
                             S->pn.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
                             S->timing ? S->ev1 : nullptr));
     S->timed_valid = S->timing;
-    S->counts_pending = S->counting;
+    S->counts_pending = S->counting ? 1 : 0;
     return IBL_OK;
 }
 
@@ -571,13 +586,88 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
     const uint32_t n_units = (n_oct + 63) / 64;
     const uint32_t mine = shard < n_units ? (n_units - shard + n_shards - 1) / n_shards : 0;
     S->last_counts[0] = (uint64_t)mine * 64 * 8 * n_patches;
-    S->last_counts[3] = 0;
+    S->last_counts[3] = S->last_counts[4] = 0;
     S->last_counts[1] = S->last_counts[2] = 0;
-    S->counts_pending = false;
+    S->counts_pending = 0;
     if (mine == 0) { S->timed_valid = false; return IBL_OK; }
     if (int rc = ensure(S->units, (size_t)mine * sizeof(uint32_t))) return rc;
     HIP_TRY(ibl::octet_units_strided_launch(shard, n_shards, mine, (uint32_t*)S->units.ptr, pick(stream)));
     return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, mine, 0, n_out, d_out, pick(stream));
+}
+
+// ---- sharding -------------------------------------------------------------------
+
+namespace {
+
+// The partition the shard entry points use for this cube (it follows the kernel family that
+// serves the sizes).
+int shard_map(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels, uint32_t n_shards,
+              ibl::ShardMap* m) {
+    read_tuning_once();
+    if (kind != IBL_SHARD_LAMBERTIAN && kind != IBL_SHARD_GGX) return fail(IBL_EINVAL, "shard: unknown kind %d", kind);
+    if (int rc = check_cube(in_w, in_w, "shard input")) return rc;
+    if (int rc = check_cube(out_w, out_w, "shard output")) return rc;
+    if (n_shards == 0) return fail(IBL_EINVAL, "shard: no shards");
+    m->out_w = out_w;
+    m->n_shards = n_shards;
+    m->partition = ibl::SHARD_RANGE;
+    m->tw = 1;
+    if (kind == IBL_SHARD_LAMBERTIAN) {
+        if (use_octets(in_w, out_w)) { m->partition = ibl::SHARD_LAMB_OCT; m->tw = ibl::lambertian_oct_tile_edge(out_w); }
+    } else {
+        if (in_w < 16) return fail(IBL_EINVAL, "ggx: input faces must be at least 16x16 (patch size would be 0), got %u", in_w);
+        if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
+            return fail(IBL_EINVAL, "ggx: level %u of %u is out of range", mip_level, mip_levels);
+        const ibl::GgxLevel lv = ibl::ggx_level_params(mip_level, mip_levels, in_w, in_w);
+        if (!g_tuning.no_octets && ibl::ggx_octets_eligible(in_w, out_w, lv.patch)) {
+            m->partition = ibl::SHARD_GGX_OCT;
+            m->tw = ibl::ggx_oct_tile_edge(out_w);
+        }
+    }
+    return IBL_OK;
+}
+
+}  // namespace
+
+uint32_t ibl_shard_texels(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                          uint32_t n_shards) {
+    ibl::ShardMap m;
+    if (shard_map(kind, in_w, out_w, mip_level, mip_levels, n_shards, &m)) return 0;
+    return ibl::shard_slots(m);
+}
+
+int ibl_shard_indices(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                      uint32_t shard, uint32_t n_shards, uint32_t* indices) {
+    ibl::ShardMap m;
+    if (int rc = shard_map(kind, in_w, out_w, mip_level, mip_levels, n_shards, &m)) return rc;
+    if (shard >= n_shards) return fail(IBL_EINVAL, "shard %u of %u", shard, n_shards);
+    if (!indices) return fail(IBL_EINVAL, "shard_indices: null pointer");
+    ibl::shard_indices(m, shard, indices);
+    return IBL_OK;
+}
+
+int ibl_shard_pack_dev(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                       uint32_t shard, uint32_t n_shards, uint32_t texel_bytes, const void* d_cube, void* d_packed,
+                       void* stream) {
+    if (int rc = check_ready()) return rc;
+    ibl::ShardMap m;
+    if (int rc = shard_map(kind, in_w, out_w, mip_level, mip_levels, n_shards, &m)) return rc;
+    if (shard >= n_shards) return fail(IBL_EINVAL, "shard %u of %u", shard, n_shards);
+    if (texel_bytes != 4 && texel_bytes != 16) return fail(IBL_EINVAL, "shard_pack: texels of %u bytes (4 or 16)", texel_bytes);
+    if (!d_cube || !d_packed) return fail(IBL_EINVAL, "shard_pack: null pointer");
+    HIP_TRY(ibl::shard_pack_launch(m, shard, texel_bytes, d_cube, d_packed, pick(stream)));
+    return IBL_OK;
+}
+
+int ibl_shard_unpack_dev(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                         uint32_t n_shards, uint32_t texel_bytes, const void* d_packed_all, void* d_cube, void* stream) {
+    if (int rc = check_ready()) return rc;
+    ibl::ShardMap m;
+    if (int rc = shard_map(kind, in_w, out_w, mip_level, mip_levels, n_shards, &m)) return rc;
+    if (texel_bytes != 4 && texel_bytes != 16) return fail(IBL_EINVAL, "shard_unpack: texels of %u bytes (4 or 16)", texel_bytes);
+    if (!d_packed_all || !d_cube) return fail(IBL_EINVAL, "shard_unpack: null pointer");
+    HIP_TRY(ibl::shard_unpack_launch(m, texel_bytes, d_packed_all, d_cube, pick(stream)));
+    return IBL_OK;
 }
 
 int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
@@ -591,10 +681,10 @@ int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, ui
         return fail(IBL_EINVAL, "brdf_lut: unknown jitter mode %d", jitter_mode);
     if (int rc = check_range(cell_begin, cell_count, (uint64_t)n_rough * n_cos, "brdf_lut")) return rc;
     S->last_counts[0] = 0;
-    S->last_counts[3] = 0;
+    S->last_counts[3] = S->last_counts[4] = 0;
     S->last_counts[1] = (uint64_t)cell_count * samples_sqrt * samples_sqrt;
     S->last_counts[2] = 0;
-    S->counts_pending = false;
+    S->counts_pending = 0;
     hipStream_t s = pick(stream);
     HIP_TRY(ibl::brdf_lut_launch(n_rough, n_cos, samples_sqrt, seed, jitter_mode, cell_begin, cell_count, d_out, s,
                                  S->timing ? S->ev0 : nullptr, S->timing ? S->ev1 : nullptr));
@@ -666,9 +756,9 @@ int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t ou
     if (!(lod_bias > -64.0f && lod_bias < 64.0f)) return fail(IBL_EINVAL, "ggx_sampled: lod bias out of range");
     if (int rc = check_range(out_begin, out_count, (uint64_t)out_w * out_w * 6, "ggx_sampled")) return rc;
     S->last_counts[0] = 0;
-    S->last_counts[3] = 0;
+    S->last_counts[3] = S->last_counts[4] = 0;
     S->last_counts[1] = S->last_counts[2] = (uint64_t)out_count * n_samples;
-    S->counts_pending = false;
+    S->counts_pending = 0;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
     HIP_TRY(ibl::ggx_sampled_launch(d_pyramid, in_w, out_w, mip_level, mip_levels, n_samples, lod_bias, out_begin,
                                     out_count, d_out, pick(stream), S->timing ? S->ev0 : nullptr,
@@ -826,6 +916,49 @@ int ibl_bake_png_rows(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downsca
 }
 
 namespace {
+
+ibl_progress_fn g_progress = nullptr;
+void* g_progress_user = nullptr;
+std::mutex g_progress_mutex;
+
+void report_done(int cube) {
+    if (!g_progress) return;
+    std::lock_guard<std::mutex> lock(g_progress_mutex);
+    g_progress(cube, g_progress_user);
+}
+
+struct BakeJob {
+    const uint8_t* rgbe_in;
+    uint32_t w, input_downscale, cubemap_size, ggx_samples;
+    float lod_bias;
+    bool png_rows;
+    uint8_t* lambertian_out;
+    uint8_t* ggx_out;
+    uint32_t mips;      // GGX levels to bake (0: none)
+};
+
+// The environment of a bake on the current device: RGBE strip in, decoded and (if asked) box-filtered.
+// Device layout of the staging-in block: [rgbe bytes][full float cube][downscaled float cube].
+int bake_environment(const BakeJob& job, float** d_env, uint32_t* env_w) {
+    const uint32_t w = job.w, n_full = w * w * 6;
+    const uint32_t dw = w / job.input_downscale, n_ds = dw * dw * 6;
+    const size_t off_full = ((size_t)n_full * 4 + 255) & ~(size_t)255;
+    const size_t off_ds = off_full + (size_t)n_full * 16;
+    const size_t in_total = off_ds + (job.input_downscale > 1 ? (size_t)n_ds * 16 : 0);
+    if (int rc = ensure(S->stage_in, in_total)) return rc;
+    char* base = (char*)S->stage_in.ptr;
+    HIP_TRY(hipMemcpyAsync(base, job.rgbe_in, (size_t)n_full * 4, hipMemcpyHostToDevice, S->stream));
+    float* d_full = (float*)(base + off_full);
+    *d_env = d_full;
+    *env_w = dw;
+    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)base, d_full, n_full, nullptr)) return rc;
+    if (job.input_downscale > 1) {
+        *d_env = (float*)(base + off_ds);
+        if (int rc = ibl_downscale_dev(d_full, w, w, job.input_downscale, *d_env, nullptr)) return rc;
+    }
+    return IBL_OK;
+}
+
 // pixels: the RGBE texels of one finished cube (n of them, faces of edge `edge`); hands them to the
 // caller as they are or as PNG scanlines, and returns the number of bytes written to dst.
 int emit(const float* d_f, uint8_t* d_e, uint8_t* d_rows, uint32_t edge, bool png_rows, uint8_t* dst, size_t* written) {
@@ -844,6 +977,177 @@ int emit(const float* d_f, uint8_t* d_e, uint8_t* d_rows, uint32_t edge, bool pn
     return IBL_OK;
 }
 
+// The whole bake on the current device.
+int bake_single(const BakeJob& job) {
+    const uint32_t w = job.w;
+    float* d_env = nullptr;
+    uint32_t dw = 0;
+    if (int rc = bake_environment(job, &d_env, &dw)) return rc;
+    const uint32_t n_lamb = job.cubemap_size * job.cubemap_size * 6;
+    uint32_t n_max = job.lambertian_out ? n_lamb : 0;
+    if (job.mips) { uint32_t n1 = (w / 2) * (w / 2) * 6; if (n1 > n_max) n_max = n1; }
+    if (n_max == 0) return IBL_OK;
+    // Staging-out block: [float cube of the largest output][its RGBE bytes][its PNG scanlines]
+    const size_t off_bytes = (size_t)n_max * 16;
+    const size_t off_rows = off_bytes + (size_t)n_max * 4;
+    if (int rc = ensure(S->stage_out, off_rows + (job.png_rows ? (size_t)n_max * 4 + (size_t)n_max : 0))) return rc;
+    float* d_f = (float*)S->stage_out.ptr;
+    uint8_t* d_e = (uint8_t*)S->stage_out.ptr + off_bytes;
+    uint8_t* d_rows = (uint8_t*)S->stage_out.ptr + off_rows;
+    size_t written = 0;
+    if (job.lambertian_out) {
+        if (int rc = ibl_lambertian_dev(d_env, dw, dw, job.cubemap_size, 0, n_lamb, d_f, nullptr)) return rc;
+        if (int rc = emit(d_f, d_e, d_rows, job.cubemap_size, job.png_rows, job.lambertian_out, &written)) return rc;
+        report_done(0);
+    }
+    if (job.mips && job.ggx_samples) {      // sampled mode: one pyramid of the (downscaled) environment for all levels
+        if (int rc = ensure(S->b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
+        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)S->b.ptr, nullptr)) return rc;
+    }
+    size_t out_off = 0;
+    uint32_t mw = w / 2;
+    for (uint32_t m = 1; m <= job.mips; m++, mw /= 2) {
+        const uint32_t n_m = mw * mw * 6;
+        if (job.ggx_samples) {
+            if (int rc = ibl_ggx_level_sampled_dev((const float*)S->b.ptr, dw, mw, m, job.mips, job.ggx_samples,
+                                                   job.lod_bias, 0, n_m, d_f, nullptr)) return rc;
+        } else if (int rc = ibl_ggx_level_dev(d_env, dw, dw, mw, mw, m, job.mips, 0, n_m, d_f, nullptr)) return rc;
+        if (int rc = emit(d_f, d_e, d_rows, mw, job.png_rows, job.ggx_out + out_off, &written)) return rc;
+        out_off += written;
+        report_done((int)m);
+    }
+    return IBL_OK;
+}
+
+// ---- the bake on several devices of one process ----------------------------------------
+// One host thread per initialised device.  Every device decodes the strip for itself, computes
+// its shard of every cube (the partition of the *_shard_dev entry points), encodes it, packs its
+// texels (ibl_shard_pack_dev) and copies them to the host, where the thread scatters them into
+// the cube's RGBE bytes: shards are disjoint, so the threads write different words.  A texel
+// does not depend on the number of devices, so the bytes are those of the one-device bake.
+
+struct SharedCube {
+    uint32_t edge = 0;
+    uint8_t* bytes = nullptr;              // the cube's RGBE texels on the host (caller's buffer or temporary)
+    std::atomic<int> waiting{0};           // devices that have not delivered their shard yet
+};
+
+int bake_shard(const BakeJob& job, uint32_t shard, uint32_t n_shards, std::vector<SharedCube>& cubes) {
+    const uint32_t w = job.w;
+    float* d_env = nullptr;
+    uint32_t dw = 0;
+    if (int rc = bake_environment(job, &d_env, &dw)) return rc;
+    uint32_t n_max = 0;
+    for (const SharedCube& c : cubes) if (c.edge * c.edge * 6 > n_max) n_max = c.edge * c.edge * 6;
+    if (n_max == 0) return IBL_OK;
+    // Staging-out block: [float cube][its RGBE bytes][this shard's packed RGBE texels]
+    const size_t off_bytes = (size_t)n_max * 16;
+    const size_t off_packed = off_bytes + (size_t)n_max * 4;
+    if (int rc = ensure(S->stage_out, off_packed + (size_t)n_max * 4 + 4096)) return rc;
+    float* d_f = (float*)S->stage_out.ptr;
+    uint8_t* d_e = (uint8_t*)S->stage_out.ptr + off_bytes;
+    uint8_t* d_packed = (uint8_t*)S->stage_out.ptr + off_packed;
+    if (job.mips && job.ggx_samples) {
+        if (int rc = ensure(S->b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
+        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)S->b.ptr, nullptr)) return rc;
+    }
+    std::vector<uint32_t> packed, slots;
+    for (size_t ci = 0; ci < cubes.size(); ci++) {
+        SharedCube& cube = cubes[ci];
+        const bool lambertian = job.lambertian_out && ci == 0;
+        const uint32_t m = (uint32_t)ci + (job.lambertian_out ? 0u : 1u);     // GGX level of this cube
+        const uint32_t edge = cube.edge, n_out = edge * edge * 6;
+        ibl::ShardMap map;
+        if (lambertian) {
+            if (int rc = shard_map(IBL_SHARD_LAMBERTIAN, dw, edge, 1, 1, n_shards, &map)) return rc;
+            if (int rc = ibl_lambertian_shard_dev(d_env, dw, dw, edge, shard, n_shards, d_f, nullptr)) return rc;
+        } else if (job.ggx_samples) {       // sampled mode: plain texel ranges
+            map.partition = ibl::SHARD_RANGE; map.out_w = edge; map.tw = 1; map.n_shards = n_shards;
+            const uint32_t per = (n_out + n_shards - 1) / n_shards;
+            const uint32_t begin = shard * per < n_out ? shard * per : n_out;
+            const uint32_t count = per < n_out - begin ? per : n_out - begin;
+            if (int rc = ibl_ggx_level_sampled_dev((const float*)S->b.ptr, dw, edge, m, job.mips, job.ggx_samples,
+                                                   job.lod_bias, begin, count, d_f, nullptr)) return rc;
+        } else {
+            if (int rc = shard_map(IBL_SHARD_GGX, dw, edge, m, job.mips, n_shards, &map)) return rc;
+            if (int rc = ibl_ggx_level_shard_dev(d_env, dw, dw, edge, edge, m, job.mips, shard, n_shards, d_f, nullptr)) return rc;
+        }
+        if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n_out, nullptr)) return rc;
+        const uint32_t per = ibl::shard_slots(map);
+        HIP_TRY(ibl::shard_pack_launch(map, shard, 4, d_e, d_packed, S->stream));
+        packed.resize(per);
+        slots.resize(per);
+        HIP_TRY(hipMemcpyAsync(packed.data(), d_packed, (size_t)per * 4, hipMemcpyDeviceToHost, S->stream));
+        ibl::shard_indices(map, shard, slots.data());          // host arithmetic, while the device works
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        uint32_t* dst = (uint32_t*)cube.bytes;
+        for (uint32_t k = 0; k < per; k++)
+            if (slots[k] != 0xffffffffu) dst[slots[k]] = packed[k];
+        if (cube.waiting.fetch_sub(1) == 1 && !job.png_rows) report_done(lambertian ? 0 : (int)m);
+    }
+    (void)w;
+    return IBL_OK;
+}
+
+// rehearse > 1: one device plays that many shards one after the other (the way to run the
+// shard, pack and scatter code on a machine with one GPU; the tests use it).
+int bake_multi(const BakeJob& job, std::vector<int> devices, uint32_t rehearse) {
+    if (rehearse > 1) devices.assign(rehearse, devices[0]);
+    const uint32_t n = (uint32_t)devices.size();
+    std::vector<SharedCube> cubes((job.lambertian_out ? 1 : 0) + job.mips);
+    std::vector<std::vector<uint8_t>> temp(cubes.size());          // PNG mode: the RGBE texels wait here for the filter
+    {
+        size_t ci = 0, off = 0;
+        if (job.lambertian_out) { cubes[ci].edge = job.cubemap_size; cubes[ci].bytes = job.lambertian_out; ci++; }
+        uint32_t mw = job.w / 2;
+        for (uint32_t m = 1; m <= job.mips; m++, mw /= 2, ci++) {
+            cubes[ci].edge = mw;
+            cubes[ci].bytes = job.ggx_out + off;
+            off += (size_t)mw * mw * 6 * 4;
+        }
+        for (size_t i = 0; i < cubes.size(); i++) {
+            cubes[i].waiting = (int)n;
+            if (job.png_rows) {
+                temp[i].assign((size_t)cubes[i].edge * cubes[i].edge * 6 * 4, 0);
+                cubes[i].bytes = temp[i].data();
+            }
+        }
+    }
+    std::vector<int> rcs(n, IBL_OK);
+    std::vector<std::string> messages(n);
+    std::vector<std::thread> threads;
+    for (uint32_t i = 0; i < n; i++) {
+        threads.emplace_back([&, i]() {
+            int rc = IBL_OK;
+            if (hipSetDevice(devices[i]) != hipSuccess) rc = fail(IBL_EHIP, "hipSetDevice(%d) failed", devices[i]);
+            if (!rc) rc = check_ready();
+            if (!rc) rc = bake_shard(job, i, n, cubes);
+            if (rc && S) (void)hipStreamSynchronize(S->stream);
+            rcs[i] = rc;
+            if (rc) messages[i] = g_err;
+        });
+        if (rehearse > 1) threads.back().join();       // one device: one shard at a time
+    }
+    for (std::thread& t : threads) if (t.joinable()) t.join();
+    for (uint32_t i = 0; i < n; i++)
+        if (rcs[i]) return fail(rcs[i], "device %d: %s", devices[i], messages[i].c_str());
+    if (!job.png_rows) return IBL_OK;
+    // PNG mode: the first device filters every assembled cube
+    HIP_TRY(hipSetDevice(devices[0]));
+    if (int rc = check_ready()) return rc;
+    size_t lam_off = 0, ggx_off = 0;
+    for (size_t ci = 0; ci < cubes.size(); ci++) {
+        const bool lambertian = job.lambertian_out && ci == 0;
+        const uint32_t edge = cubes[ci].edge;
+        uint8_t* dst = lambertian ? job.lambertian_out + lam_off : job.ggx_out + ggx_off;
+        if (int rc = ibl_png_filter_rows(cubes[ci].bytes, edge, edge * 6, dst)) return rc;
+        const size_t bytes = (size_t)ibl_png_rows_bytes(edge, edge * 6);
+        if (lambertian) lam_off += bytes; else ggx_off += bytes;
+        report_done(lambertian ? 0 : (int)(ci + (job.lambertian_out ? 0 : 1)));
+    }
+    return IBL_OK;
+}
+
 int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size, uint32_t ggx_samples,
          float lod_bias, bool png_rows, uint8_t* lambertian_out, uint8_t* ggx_out) {
     if (int rc = check_ready()) return rc;
@@ -855,57 +1159,37 @@ int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t 
         return fail(IBL_EINVAL, "bake: downscale %u does not divide the face width %u", input_downscale, w);
     if (cubemap_size == 0) return fail(IBL_EINVAL, "bake: cubemap size 0");
     if (lambertian_out) if (int rc = check_cube(cubemap_size, cubemap_size, "bake lambertian output")) return rc;
-    const uint32_t n_full = w * w * 6;
-    const uint32_t dw = w / input_downscale;
-    const uint32_t n_ds = dw * dw * 6;
-    const uint32_t n_lamb = cubemap_size * cubemap_size * 6;
-    // Device layout of the staging-in block: [rgbe bytes][full float cube][downscaled float cube]
-    const size_t off_full = ((size_t)n_full * 4 + 255) & ~(size_t)255;
-    const size_t off_ds = off_full + (size_t)n_full * 16;
-    const size_t in_total = off_ds + (input_downscale > 1 ? (size_t)n_ds * 16 : 0);
-    if (int rc = ensure(S->stage_in, in_total)) return rc;
-    char* base = (char*)S->stage_in.ptr;
-    HIP_TRY(hipMemcpyAsync(base, rgbe_in, (size_t)n_full * 4, hipMemcpyHostToDevice, S->stream));
-    float* d_full = (float*)(base + off_full);
-    float* d_env = d_full;
-    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)base, d_full, n_full, nullptr)) return rc;
-    if (input_downscale > 1) {
-        d_env = (float*)(base + off_ds);
-        if (int rc = ibl_downscale_dev(d_full, w, w, input_downscale, d_env, nullptr)) return rc;
+    BakeJob job;
+    job.rgbe_in = rgbe_in; job.w = w; job.input_downscale = input_downscale; job.cubemap_size = cubemap_size;
+    job.ggx_samples = ggx_samples; job.lod_bias = lod_bias; job.png_rows = png_rows;
+    job.lambertian_out = lambertian_out; job.ggx_out = ggx_out;
+    job.mips = ggx_out ? ibl_ggx_mip_levels(w, w, cubemap_size) : 0;
+    if (job.mips && w / input_downscale < 16)
+        return fail(IBL_EINVAL, "ggx: input faces must be at least 16x16 (patch size would be 0), got %u", w / input_downscale);
+    std::vector<int> devices;
+    for (int d = 0; d < MAX_DEVICES; d++) if (g_states[d].ready) devices.push_back(d);
+    int current = -1;
+    (void)hipGetDevice(&current);
+    int rc;
+    if (devices.size() > 1 || g_tuning.bake_rehearse_shards > 1) {
+        if (devices.size() > 1) rc = bake_multi(job, devices, 0);
+        else rc = bake_multi(job, std::vector<int>(1, S->device), (uint32_t)g_tuning.bake_rehearse_shards);
+        if (current >= 0) (void)hipSetDevice(current);
+        (void)check_ready();
+    } else {
+        rc = bake_single(job);
     }
-    uint32_t mips = ggx_out ? ibl_ggx_mip_levels(w, w, cubemap_size) : 0;
-    uint32_t n_max = lambertian_out ? n_lamb : 0;
-    if (mips) { uint32_t n1 = (w / 2) * (w / 2) * 6; if (n1 > n_max) n_max = n1; }
-    if (n_max == 0) { HIP_TRY(hipStreamSynchronize(S->stream)); return IBL_OK; }
-    // Staging-out block: [float cube of the largest output][its RGBE bytes][its PNG scanlines]
-    const size_t off_bytes = (size_t)n_max * 16;
-    const size_t off_rows = off_bytes + (size_t)n_max * 4;
-    if (int rc = ensure(S->stage_out, off_rows + (png_rows ? (size_t)n_max * 4 + (size_t)n_max : 0))) return rc;
-    float* d_f = (float*)S->stage_out.ptr;
-    uint8_t* d_e = (uint8_t*)S->stage_out.ptr + off_bytes;
-    uint8_t* d_rows = (uint8_t*)S->stage_out.ptr + off_rows;
-    size_t written = 0;
-    if (lambertian_out) {
-        if (int rc = ibl_lambertian_dev(d_env, dw, dw, cubemap_size, 0, n_lamb, d_f, nullptr)) return rc;
-        if (int rc = emit(d_f, d_e, d_rows, cubemap_size, png_rows, lambertian_out, &written)) return rc;
-    }
-    if (mips && ggx_samples) {      // sampled mode: one pyramid of the (downscaled) environment for all levels
-        if (int rc = ensure(S->b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
-        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)S->b.ptr, nullptr)) return rc;
-    }
-    size_t out_off = 0;
-    uint32_t mw = w / 2;
-    for (uint32_t m = 1; m <= mips; m++, mw /= 2) {
-        const uint32_t n_m = mw * mw * 6;
-        if (ggx_samples) {
-            if (int rc = ibl_ggx_level_sampled_dev((const float*)S->b.ptr, dw, mw, m, mips, ggx_samples, lod_bias, 0, n_m,
-                                                   d_f, nullptr)) return rc;
-        } else if (int rc = ibl_ggx_level_dev(d_env, dw, dw, mw, mw, m, mips, 0, n_m, d_f, nullptr)) return rc;
-        if (int rc = emit(d_f, d_e, d_rows, mw, png_rows, ggx_out + out_off, &written)) return rc;
-        out_off += written;
-    }
-    return IBL_OK;
+    // the copy from the caller's strip may still be queued when a later step has failed
+    if (rc && S) (void)hipStreamSynchronize(S->stream);
+    return rc;
 }
 }  // namespace
+
+int ibl_set_progress(ibl_progress_fn fn, void* user) {
+    std::lock_guard<std::mutex> lock(g_progress_mutex);
+    g_progress = fn;
+    g_progress_user = user;
+    return IBL_OK;
+}
 
 }  // extern "C"

@@ -458,7 +458,8 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
         if (lane == 0) {
             atomicAdd(&counts[1], tot_tested);
             atomicAdd(&counts[2], tot_accepted);
-            atomicAdd(&counts[3], tot_walked);       // records this wave evaluated (64 lanes each)
+            atomicAdd(&counts[3], tot_walked);       // records this wave evaluated (64 lanes each),
+            atomicAdd(&counts[4], tot_walked);       // one sign pattern per record and walk
         }
     }
 }

@@ -18,6 +18,7 @@ struct Tuning {
     int lamb_oct_affine = -1;      // octet Lambertian kernel: 1 / 0 force / forbid dealing slots to the XCDs (-1: automatic)
     double ggx_waves = 0.0;        // octet GGX kernel: waves per level to aim for (0: automatic)
     int ggx_xcd_slices = -1;       // octet GGX kernel: 1 / 0 force / forbid dealing runs to the XCDs (-1: automatic)
+    int bake_rehearse_shards = 0;  // ibl_bake_*: > 1 makes one device play that many shards in turn (tests)
     float ggx_core = 2.0f;         // multiple of alpha^2 below which the reference's own denominator is repeated
 };
 Tuning& tuning();
@@ -67,8 +68,8 @@ LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks);
 hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
                                  const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
                                  uint32_t out_begin, uint32_t out_count,
-                                 float* d_out, void* d_rec, double* d_partial, hipStream_t stream,
-                                 hipEvent_t ev0, hipEvent_t ev1);
+                                 float* d_out, void* d_rec, double* d_partial, unsigned long long* d_counts,
+                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
 struct GgxLevel {          // cube.cpp:161-175
     float roughness, alpha2, cutoff;
@@ -119,6 +120,22 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
                           const uint32_t* d_units, uint32_t out_begin, uint32_t out_count,
                           float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
                           hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+
+// The partition of a cube's output texels into shards (sharding.hip).
+enum ShardPartition { SHARD_RANGE = 0, SHARD_LAMB_OCT = 1, SHARD_GGX_OCT = 2 };
+struct ShardMap {
+    uint32_t partition;   // ShardPartition
+    uint32_t out_w;       // face edge of the cube
+    uint32_t tw;          // tile edge of the tile-major octet order (octet partitions)
+    uint32_t n_shards;
+};
+uint32_t shard_slots(const ShardMap& m);                                      // slots per shard, padding included
+void shard_indices(const ShardMap& m, uint32_t shard, uint32_t* indices);   // host: texel of every slot, 0xffffffff = padding
+// elem_bytes 16 (float4 texels) or 4 (RGBE texels)
+hipError_t shard_pack_launch(const ShardMap& m, uint32_t shard, uint32_t elem_bytes, const void* d_full, void* d_packed,
+                             hipStream_t stream);
+hipError_t shard_unpack_launch(const ShardMap& m, uint32_t elem_bytes, const void* d_packed_all, void* d_full,
+                               hipStream_t stream);
 
 // Sampled GGX mode (ggx_sampled.hip): box pyramid of the environment and the level kernel.
 uint32_t pyramid_levels(uint32_t w);

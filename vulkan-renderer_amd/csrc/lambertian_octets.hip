@@ -127,12 +127,14 @@ __device__ __forceinline__ uint32_t octet_range_mask(uint32_t axis, uint32_t j, 
 //              chip, but the 24 extra FP64 sums cost a wave per SIMD and 12 % of the speed (measured
 //              on 1024 -> 128: 22.1 against 19.6 ms).  Used where the workspace must be small.
 // Both give the same bits.
-template <bool RUN>
+// COUNT: the wavefronts also count the records they walk and the sign patterns they evaluate
+// (what the arithmetic actually executed is priced by).
+template <bool RUN, bool COUNT>
 __global__ __launch_bounds__(OCT_THREADS, RUN ? OCT_MIN_WAVES_RUN : OCT_MIN_WAVES) void lambertian_oct_pairs(
     const float4* __restrict__ rec, uint32_t n_oct_in, uint32_t slice_len, uint32_t n_slices,
     uint32_t out_size, const uint32_t* __restrict__ block_list, uint32_t oct_begin, uint32_t oct_end,
     uint32_t out_blocks, uint32_t xcd_affine, uint32_t out_begin, uint32_t out_count,
-    void* __restrict__ partial_out) {
+    void* __restrict__ partial_out, unsigned long long* __restrict__ counts) {
     __shared__ float4 s_rec[2][OCT_TILE * OCT_REC];
 
     const uint32_t tid = threadIdx.x;
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(OCT_THREADS, RUN ? OCT_MIN_WAVES_RUN : OCT_MIN_WAVE
         }
     }
     const unsigned long long full = __ballot(true);     // the wave's live lanes
+    unsigned long long n_records = 0, n_patterns = 0;    // wave-uniform
 
     for (uint32_t slice = sl0; slice < sl1; slice++) {
         const uint32_t in0 = slice * slice_len;
@@ -230,24 +233,28 @@ __global__ __launch_bounds__(OCT_THREADS, RUN ? OCT_MIN_WAVES_RUN : OCT_MIN_WAVE
                         }
                 };
                 accumulate(std::integral_constant<int, 0>{}, s1 + cc);      // (+,+,+): always positive
+                if (COUNT) { n_records += 1; n_patterns += 1; }
                 // The other six patterns come in three pairs of opposite sign, (t, 7 - t): per lane
                 // exactly one of a pair is positive (cube.cpp:115 drops the other).  When the whole
                 // wave agrees on which, the other one's 24 FMAs are skipped; (-,-,-) never counts.
                 {
                     const float v = cc - s2;                                 // (-,+,+) = -a+b+c; (+,-,-) is -v
                     const unsigned long long pos = __ballot(v > 0.0f);
+                    if (COUNT) n_patterns += (pos != 0ull ? 1u : 0u) + (pos != full ? 1u : 0u);
                     if (pos != 0ull) accumulate(std::integral_constant<int, 1>{}, sub_clamp01(cc, s2));
                     if (pos != full) accumulate(std::integral_constant<int, 6>{}, sub_clamp01(s2, cc));
                 }
                 {
                     const float v = s2 + cc;                                 // (+,-,+) = a-b+c; (-,+,-) is -v
                     const unsigned long long pos = __ballot(v > 0.0f);
+                    if (COUNT) n_patterns += (pos != 0ull ? 1u : 0u) + (pos != full ? 1u : 0u);
                     if (pos != 0ull) accumulate(std::integral_constant<int, 2>{}, add_clamp01(s2, cc));
                     if (pos != full) accumulate(std::integral_constant<int, 5>{}, neg_sub_clamp01(s2, cc));
                 }
                 {
                     const float v = s1 - cc;                                 // (+,+,-) = a+b-c; (-,-,+) is -v
                     const unsigned long long pos = __ballot(v > 0.0f);
+                    if (COUNT) n_patterns += (pos != 0ull ? 1u : 0u) + (pos != full ? 1u : 0u);
                     if (pos != 0ull) accumulate(std::integral_constant<int, 4>{}, sub_clamp01(s1, cc));
                     if (pos != full) accumulate(std::integral_constant<int, 3>{}, sub_clamp01(cc, s1));
                 }
@@ -283,6 +290,10 @@ __global__ __launch_bounds__(OCT_THREADS, RUN ? OCT_MIN_WAVES_RUN : OCT_MIN_WAVE
                 if (RUN) ((double*)partial_out)[at] = gacc[k][s];
                 else ((float*)partial_out)[at] = (float)dacc[k][s];
             }
+    }
+    if (COUNT && (tid & 63u) == 0u) {
+        atomicAdd(&counts[3], n_records);
+        atomicAdd(&counts[4], n_patterns);
     }
 }
 
@@ -422,8 +433,8 @@ LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks) {
 hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
                                  const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
                                  uint32_t out_begin, uint32_t out_count,
-                                 float* d_out, void* d_rec, double* d_partial, hipStream_t stream,
-                                 hipEvent_t ev0, hipEvent_t ev1) {
+                                 float* d_out, void* d_rec, double* d_partial, unsigned long long* d_counts,
+                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     lambertian_oct_prep<<<(pl.n_oct_in + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, in_w, pl.n_oct_in,
                                                                        (float4*)d_rec);
     const uint32_t oct_local = pl.out_blocks * OCT_THREADS;
@@ -435,14 +446,13 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
     // workspace: the run sums first, then (slice form) the slice sums
     double* d_runs = d_partial;
     float* d_slices = (float*)(d_partial + (size_t)pl.n_runs * 24 * oct_local);
-    if (pl.run)
-        lambertian_oct_pairs<true><<<grid, OCT_THREADS, 0, stream>>>(
+    auto go = [&](auto kernel, void* d_store) {
+        kernel<<<grid, OCT_THREADS, 0, stream>>>(
             (const float4*)d_rec, pl.n_oct_in, pl.slice_len, pl.n_slices, out_size, d_block_list, oct_begin, oct_end,
-            pl.out_blocks, affine, out_begin, out_count, d_runs);
-    else
-        lambertian_oct_pairs<false><<<grid, OCT_THREADS, 0, stream>>>(
-            (const float4*)d_rec, pl.n_oct_in, pl.slice_len, pl.n_slices, out_size, d_block_list, oct_begin, oct_end,
-            pl.out_blocks, affine, out_begin, out_count, d_slices);
+            pl.out_blocks, affine, out_begin, out_count, d_store, d_counts);
+    };
+    if (pl.run) { if (d_counts) go(lambertian_oct_pairs<true, true>, d_runs); else go(lambertian_oct_pairs<true, false>, d_runs); }
+    else        { if (d_counts) go(lambertian_oct_pairs<false, true>, d_slices); else go(lambertian_oct_pairs<false, false>, d_slices); }
     if (ev1) (void)hipEventRecord(ev1, stream);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);
     if (!pl.run)

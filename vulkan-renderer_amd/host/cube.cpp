@@ -16,8 +16,10 @@
 //
 // Differences from the reference, all outside the numerics: errors end the
 // process with a message and EXIT_FAILURE instead of an uncaught exception
-// (the reference's main has no try/catch), the progress bars are printed when a
-// step has finished rather than while it runs, and IBL_LUT_SEED may fix the
+// (the reference's main has no try/catch), every progress bar is printed, and its
+// file written, when the library reports that cube finished (while the GPUs work on
+// the next one) rather than growing while the cube is computed, the bake runs on
+// every visible GPU (IBL_CUBE_DEVICES=n limits it), and IBL_LUT_SEED may fix the
 // jitter seed that the reference draws from std::random_device (cube.cpp:342).
 #include "ibl_hip.h"
 #include "png_io.hpp"
@@ -85,6 +87,45 @@ struct StageClock {
     }
 };
 
+// What the progress callback needs to print a cube's bar and write its file as soon as the
+// library has delivered it (the reference: cube.cpp:131-141,311-322).
+struct BakeOutputs {
+    std::filesystem::path input_path;
+    uint32_t w = 0, mips = 0, cubemap_size = 0;
+    std::vector<uint8_t> lambertian, ggx;
+    std::string error;
+
+    void cube_done(int cube) {
+        std::string err;
+        std::filesystem::path out = input_path;
+        if (cube == 0) {
+            std::cout << "Integrating Lambertian: [" << std::flush;
+            print_bar();
+            out.replace_extension(".lambertian.png");
+            if (!png_write_filtered_rows(out.string(), cubemap_size, cubemap_size * 6, lambertian.data(), lambertian.size(), err))
+                error = err;
+            return;
+        }
+        const uint32_t m = (uint32_t)cube, mw = w >> m;
+        size_t off = 0;
+        for (uint32_t k = 1; k < m; k++) off += (size_t)ibl_png_rows_bytes(w >> k, (w >> k) * 6);
+        std::cout << "Integrating GGX (Level " << m << " of " << mips << "): [" << std::flush;
+        print_bar();
+        out.replace_extension(".ggx" + std::to_string(m) + ".png");
+        if (!png_write_filtered_rows(out.string(), mw, mw * 6, ggx.data() + off, (size_t)ibl_png_rows_bytes(mw, mw * 6), err))
+            error = err;
+    }
+};
+
+void on_cube_done(int cube, void* user) { static_cast<BakeOutputs*>(user)->cube_done(cube); }
+
+// Every visible GPU takes a share of each cube (IBL_CUBE_DEVICES limits how many).
+void open_gpus() {
+    int n = 0;
+    if (const char* e = std::getenv("IBL_CUBE_DEVICES")) n = std::atoi(e);
+    check(ibl_init_all(n));
+}
+
 // The body of the reference's main after argument parsing, cube.cpp:455-516.
 void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) {
     uint32_t w = 0, h = 0;
@@ -97,38 +138,26 @@ void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) 
     if (w == 0 || h != w) PANIC("input must be a W x 6W strip of square cube faces");
     if (!opt.lambertian && !opt.ggx) return;
 
-    check(ibl_init(-1));
+    open_gpus();
     clock.lap("open the GPU");
-    const uint32_t mips = opt.ggx ? ibl_ggx_mip_levels(w, h, opt.cubemap_size) : 0;
+    BakeOutputs outs;
+    outs.input_path = input_path;
+    outs.w = w;
+    outs.cubemap_size = opt.cubemap_size;
+    outs.mips = opt.ggx ? ibl_ggx_mip_levels(w, h, opt.cubemap_size) : 0;
     // The library hands back PNG scanlines (RGBE-encoded and filtered on the device); only deflate is left to do here.
-    std::vector<uint8_t> lambertian(opt.lambertian ? (size_t)ibl_png_rows_bytes(opt.cubemap_size, opt.cubemap_size * 6) : 0);
+    outs.lambertian.resize(opt.lambertian ? (size_t)ibl_png_rows_bytes(opt.cubemap_size, opt.cubemap_size * 6) : 0);
     size_t ggx_bytes = 0;
-    for (uint32_t m = 1; m <= mips; m++) ggx_bytes += (size_t)ibl_png_rows_bytes(w >> m, (w >> m) * 6);
-    std::vector<uint8_t> ggx(ggx_bytes);
-    check(ibl_bake_png_rows(pixels.data(), w, opt.input_downscale, opt.cubemap_size, opt.ggx_samples, opt.ggx_lod_bias,
-                            opt.lambertian ? lambertian.data() : nullptr, (opt.ggx && mips) ? ggx.data() : nullptr));
-    clock.lap("bake on the GPU (copies included)");
-
-    if (opt.lambertian) {
-        std::cout << "Integrating Lambertian: [" << std::flush;
-        print_bar();
-        std::filesystem::path out = input_path;
-        out.replace_extension(".lambertian.png");
-        if (!png_write_filtered_rows(out.string(), opt.cubemap_size, opt.cubemap_size * 6, lambertian.data(), lambertian.size(), err))
-            PANIC(err);
-    }
-    size_t off = 0;
-    for (uint32_t m = 1; m <= mips; m++) {
-        const uint32_t mw = w >> m;
-        std::cout << "Integrating GGX (Level " << m << " of " << mips << "): [" << std::flush;
-        print_bar();
-        std::filesystem::path out = input_path;
-        out.replace_extension(".ggx" + std::to_string(m) + ".png");
-        const size_t n_bytes = (size_t)ibl_png_rows_bytes(mw, mw * 6);
-        if (!png_write_filtered_rows(out.string(), mw, mw * 6, ggx.data() + off, n_bytes, err)) PANIC(err);
-        off += n_bytes;
-    }
-    clock.lap("deflate and write the PNGs");
+    for (uint32_t m = 1; m <= outs.mips; m++) ggx_bytes += (size_t)ibl_png_rows_bytes(w >> m, (w >> m) * 6);
+    outs.ggx.resize(ggx_bytes);
+    check(ibl_set_progress(on_cube_done, &outs));
+    const int rc = ibl_bake_png_rows(pixels.data(), w, opt.input_downscale, opt.cubemap_size, opt.ggx_samples, opt.ggx_lod_bias,
+                                     opt.lambertian ? outs.lambertian.data() : nullptr,
+                                     (opt.ggx && outs.mips) ? outs.ggx.data() : nullptr);
+    ibl_set_progress(nullptr, nullptr);
+    check(rc);
+    if (!outs.error.empty()) PANIC(outs.error);
+    clock.lap("bake on the GPU, deflate and write the PNGs");
 }
 
 // Every environment of a scene, in the loader's numbering.
@@ -183,7 +212,7 @@ int run(int argc, char** argv) {
             opt.ggx_lod_bias = std::strtof(s.c_str(), &end);
             if (end == s.c_str() || *end != '\0') PANIC("invalid argument to --ggx-lod-bias");
         } else if (arg == "--generate-ggx-lut") {
-            check(ibl_init(-1));
+            check(ibl_init(0));
             generate_ggx_lut();
             return 0;
         } else if (arg == "--scene") {
