@@ -555,7 +555,12 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
         const double per_run = (double)units_level * GO_UNIT * GO_SUMS * sizeof(float);
         const double fit = ceil(rec_total / (double)(4u << 20));
         const double afford = floor((double)(4ull << 30) / per_run);
+        // ... and the partial sums should not be many times the bytes the level has to move anyway
+        // (32 per input texel, 16 per output texel): at most 8 times those.
+        const double algorithmic = 32.0 * pl.n_po * ps * ps * 8.0 + 16.0 * n_oct_level * 8.0;
+        const double modest = floor(8.0 * algorithmic / per_run);
         if (tuning().ggx_waves <= 0.0) {
+            if ((double)want > modest) want = modest >= 1.0 ? (uint32_t)modest : 1u;
             if (fit > (double)want) want = (uint32_t)fit;
             if ((double)want > afford) want = afford >= 1.0 ? (uint32_t)afford : 1u;
         }

@@ -139,13 +139,15 @@ __global__ __launch_bounds__(OCT_THREADS, RUN ? OCT_MIN_WAVES_RUN : OCT_MIN_WAVE
 
     const uint32_t tid = threadIdx.x;
     // Workgroups go to the 8 XCDs round-robin by their linear index and every XCD has its own
-    // L2.  With xcd_affine (slot count a multiple of 8) XCD k only ever works on slots k, k + 8,
-    // ...: every input record is then fetched into one L2 instead of all eight.
+    // L2.  With xcd_affine XCD k only ever works on slots k, k + 8, ...: every input record is
+    // then fetched into one L2 instead of all eight (the grid is padded to a multiple of 8 slots;
+    // workgroups of the padding leave at once).
     uint32_t slot, ob;
     if (xcd_affine) {
         const uint32_t seq = blockIdx.x >> 3;
         slot = (blockIdx.x & 7u) + 8u * (seq / out_blocks);
         ob = seq % out_blocks;
+        if (slot >= (RUN ? (n_slices + OCT_RUN - 1) / OCT_RUN : n_slices)) return;
     } else {
         slot = blockIdx.x / out_blocks;
         ob = blockIdx.x % out_blocks;
@@ -415,9 +417,12 @@ LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks) {
     pl.n_oct_in = 3 * (in_w / 2) * (in_w / 2);
     // Slice length depends on the input size only (range/shard independence).
     uint32_t tiles = (pl.n_oct_in + OCT_TILE - 1) / OCT_TILE;
-    // At most 512 slices: an eighth of the output blocks of the largest case (one of 8 GPUs)
-    // then still fills a GPU three times over.
-    uint32_t max_slices = tuning().lamb_oct_slices ? tuning().lamb_oct_slices : 512;
+    // At most 304 slices (300 for a 1024 x 1024 face).  More slices fill a GPU better when a call
+    // covers few output blocks (an eighth of 1024 -> 128, one of 8 GPUs: 2.52 ms with 512 slices,
+    // 2.58 with 384, 2.69 with 256; the whole cube on one GPU: 19.4 ms with any of them), fewer
+    // slices write fewer partial sums (1.18 MB each for that cube): 300 keep the kernel's memory
+    // traffic below three times the bytes it has to move anyway.
+    uint32_t max_slices = tuning().lamb_oct_slices ? tuning().lamb_oct_slices : 304;
     uint32_t tiles_per_slice = (tiles + max_slices - 1) / max_slices;
     if (tiles_per_slice < 2) tiles_per_slice = 2;
     pl.slice_len = tiles_per_slice * OCT_TILE;
@@ -439,9 +444,8 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
                                                                        (float4*)d_rec);
     const uint32_t oct_local = pl.out_blocks * OCT_THREADS;
     const uint32_t n_slots = pl.run ? pl.n_runs : pl.n_slices;
-    uint32_t affine = n_slots % 8 == 0 ? 1u : 0u;
-    if (tuning().lamb_oct_affine == 0) affine = 0u;
-    const dim3 grid(pl.out_blocks * n_slots);
+    const uint32_t affine = (n_slots >= 8 && tuning().lamb_oct_affine != 0) ? 1u : 0u;
+    const dim3 grid(pl.out_blocks * (affine ? (n_slots + 7) / 8 * 8 : n_slots));
     if (ev0) (void)hipEventRecord(ev0, stream);
     // workspace: the run sums first, then (slice form) the slice sums
     double* d_runs = d_partial;
