@@ -14,10 +14,13 @@
  *     index ((face*H + y)*W + x)*4, faces +X,-X,+Y,-Y,+Z,-Z
  *     (cube.cpp:16-29,96).  Faces are square (the reference strides input rows by
  *     the height, cube.cpp:104,264, so nothing else is meaningful).
- *   - "*_dev" functions take DEVICE pointers, enqueue on `stream` (a hipStream_t;
- *     NULL = the HIP default stream) and do not synchronise.  They use a
- *     per-device workspace the library owns, so calls on one device must not
- *     overlap in time: issue them on one stream, or order streams with events.
+ *   - "*_dev" functions take DEVICE pointers and enqueue on `stream` (a hipStream_t;
+ *     NULL = the HIP default stream).  They use per-device workspaces the library
+ *     owns, so calls on one device must not overlap in time: issue them on one
+ *     stream, or order streams with events.  The workspaces only grow: a call that
+ *     finds one too small waits for the device, frees it and allocates a larger one
+ *     (not allowed under stream capture); every other call only enqueues kernels and
+ *     does not synchronise.  ibl_reserve sizes the workspaces ahead of time.
  *   - The library keeps one state (workspaces, timer) per initialised device and
  *     every call works on the state of the calling thread's current HIP device
  *     (hipSetDevice / hipGetDevice).  The states have no locks, like the
@@ -72,6 +75,14 @@ int ibl_initialized_devices(void);
 int ibl_shutdown(void);
 const char* ibl_last_error(void);
 int ibl_device_count(void);
+
+/* Grows the current device's workspaces to what whole-cube calls of these shapes need:
+ * ibl_lambertian_dev from in_w to lambertian_size texels per face edge (0: none), and
+ * ibl_ggx_level_dev for every level of the chain of a ggx_top_w face with minimum size
+ * ggx_min_size (the tool's --cubemap-size) computed from an in_w input (ggx_top_w 0: none;
+ * in_w is ggx_top_w divided by the tool's --input-downscale).  Afterwards such calls neither
+ * allocate nor synchronise, e.g. under HIP graph capture. */
+int ibl_reserve(uint32_t in_w, uint32_t lambertian_size, uint32_t ggx_top_w, uint32_t ggx_min_size);
 
 /* ---- level geometry (host arithmetic only) ------------------------------- */
 

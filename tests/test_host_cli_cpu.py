@@ -139,7 +139,9 @@ def test_python_png_module_roundtrip(tmp_path):
         want = img.copy()
         if ct == 2:
             want[..., 3] = 255
-        np.testing.assert_array_equal(png.read_rgba8(p), want)
+        np.testing.assert_array_equal(png.read_rgba8(p), want)                    # the C++ reader behind ctypes
+        np.testing.assert_array_equal(png.read_rgba8(p, native=False), want)      # the numpy fallback
+    assert png._native() is not None, "libibl_png.so is missing: run __graft_entry__.build()"
     p = str(tmp_path / "b.png")
     png.write_rgba8(p, img)
     np.testing.assert_array_equal(read_png(p), img)

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "ibl_shutdown": ([], _int),
     "ibl_last_error": ([], ctypes.c_char_p),
     "ibl_device_count": ([], _int),
+    "ibl_reserve": ([_u32, _u32, _u32, _u32], _int),
     "ibl_ggx_mip_levels": ([_u32, _u32, _u32], _u32),
     "ibl_ggx_level_params": ([_u32, _u32, _u32, _u32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_u32)], _int),
@@ -170,6 +171,9 @@ class Ibl:
 
     def close(self):
         self.lib.ibl_shutdown()
+
+    def reserve(self, in_w, lambertian_size=0, ggx_top_w=0, ggx_min_size=16):
+        self._check(self.lib.ibl_reserve(in_w, lambertian_size, ggx_top_w, ggx_min_size))
 
     # -- geometry ---------------------------------------------------------------------
     def ggx_mip_levels(self, top_w, top_h, min_size):

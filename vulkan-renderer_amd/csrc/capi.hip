@@ -595,6 +595,55 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
     return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, mine, 0, n_out, d_out, pick(stream));
 }
 
+// Sizes the current device's workspaces for whole-cube Lambertian calls in_w -> lambertian_size
+// (0: none) and for every level of the GGX chain of a ggx_top_w face with minimum size
+// ggx_min_size computed from an in_w input (ggx_top_w 0: none), so that later *_dev calls of
+// those shapes find them large enough and neither synchronise nor allocate.
+int ibl_reserve(uint32_t in_w, uint32_t lambertian_size, uint32_t ggx_top_w, uint32_t ggx_min_size) {
+    if (int rc = check_ready()) return rc;
+    if (int rc = check_cube(in_w, in_w, "reserve input")) return rc;
+    const uint32_t n_in = in_w * in_w * 6;
+    if (lambertian_size) {
+        if (int rc = check_cube(lambertian_size, lambertian_size, "reserve lambertian output")) return rc;
+        if (use_octets(in_w, lambertian_size)) {
+            ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, ibl::lambertian_oct_blocks_total(lambertian_size));
+            if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
+            if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+            if (int rc = ensure(S->units, (size_t)pl.out_blocks * sizeof(uint32_t))) return rc;
+        } else {
+            ibl::LambertianPlan pl = ibl::lambertian_plan(n_in, lambertian_size * lambertian_size * 6);
+            if (int rc = ensure(S->a, pl.prep_bytes_a)) return rc;
+            if (int rc = ensure(S->b, pl.prep_bytes_b)) return rc;
+            if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+        }
+    }
+    if (ggx_top_w) {
+        if (in_w < 16) return fail(IBL_EINVAL, "ggx: input faces must be at least 16x16 (patch size would be 0), got %u", in_w);
+        const uint32_t mips = ibl_ggx_mip_levels(ggx_top_w, ggx_top_w, ggx_min_size);
+        for (uint32_t m = 1; m <= mips; m++) {
+            const uint32_t ow = ggx_top_w >> m;
+            if (ow == 0) break;
+            const ibl::GgxLevel lv = ibl::ggx_level_params(m, mips, in_w, in_w);
+            if (!g_tuning.no_octets && ibl::ggx_octets_eligible(in_w, ow, lv.patch)) {
+                const uint32_t n_oct = 3 * (ow / 2) * (ow / 2), units = (n_oct + ibl::GGX_OCT_UNIT - 1) / ibl::GGX_OCT_UNIT;
+                ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, ow, m, mips, units);
+                if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
+                if (int rc = ensure(S->pn, pl.pn_bytes)) return rc;
+                if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+                if (int rc = ensure(S->units, (size_t)units * sizeof(uint32_t))) return rc;
+            } else {
+                ibl::GgxPlan pl = ibl::ggx_plan(in_w, in_w, ow, ow, m, mips, ow * ow * 6);
+                if (int rc = ensure(S->a, pl.prep_bytes_a)) return rc;
+                if (int rc = ensure(S->b, pl.prep_bytes_b)) return rc;
+                if (int rc = ensure(S->pn, pl.prep_bytes_pn)) return rc;
+                if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+            }
+        }
+    }
+    if (S->counting) if (int rc = ensure(S->counts, 8 * sizeof(unsigned long long))) return rc;
+    return IBL_OK;
+}
+
 // ---- sharding -------------------------------------------------------------------
 
 namespace {

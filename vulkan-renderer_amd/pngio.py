@@ -1,16 +1,47 @@
-"""Minimal PNG reader/writer (8-bit, non-interlaced RGBA/RGB in, RGBA out) on numpy and
-zlib, for the Python-side tools.  The C++ host tool has its own (host/png_io.cpp); the
-reference goes through stb_image for the same job (cube.cpp:141,322,458)."""
+"""PNG reader/writer for the Python-side tools (RGBA out).  Reading goes through the cube
+tool's own C++ reader (host/png_io.cpp, built as libibl_png.so) when that library is present --
+strips written by the reference's tool are full of average and Paeth rows, which a Python loop
+unfilters a byte at a time -- and falls back to a small numpy/zlib reader (8-bit,
+non-interlaced RGB/RGBA) otherwise.  The reference goes through stb_image for the same job
+(cube.cpp:141,322,458)."""
+import ctypes
+import os
 import struct
 import zlib
 
 import numpy as np
 
 _SIG = b"\x89PNG\r\n\x1a\n"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libibl_png.so")
+_lib = None
 
 
-def read_rgba8(path):
+def _native():
+    global _lib
+    if _lib is None and os.path.exists(_LIB_PATH):
+        lib = ctypes.CDLL(_LIB_PATH)
+        lib.ibl_png_read_rgba8.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                           ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_char_p, ctypes.c_size_t]
+        lib.ibl_png_read_rgba8.restype = ctypes.c_int
+        lib.ibl_png_free.argtypes = [ctypes.POINTER(ctypes.c_uint8)]
+        lib.ibl_png_free.restype = None
+        _lib = lib
+    return _lib
+
+
+def read_rgba8(path, native=True):
     """-> (H, W, 4) uint8."""
+    lib = _native() if native else None
+    if lib is not None:
+        w, h = ctypes.c_uint32(), ctypes.c_uint32()
+        px = ctypes.POINTER(ctypes.c_uint8)()
+        err = ctypes.create_string_buffer(256)
+        if lib.ibl_png_read_rgba8(os.fsencode(path), ctypes.byref(w), ctypes.byref(h), ctypes.byref(px), err, 256) != 0:
+            raise ValueError(err.value.decode() or "cannot read %s" % path)
+        try:
+            return np.ctypeslib.as_array(px, shape=(h.value, w.value, 4)).copy()
+        finally:
+            lib.ibl_png_free(px)
     with open(path, "rb") as f:
         data = f.read()
     if data[:8] != _SIG:
