@@ -221,6 +221,26 @@ int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t ou
 uint64_t ibl_png_rows_bytes(uint32_t w, uint32_t h);
 int ibl_png_filter_rows_dev(const uint8_t* d_rgba8, uint32_t w, uint32_t h, uint8_t* d_rows, void* stream);
 
+/* ---- mirror-local re-projection -------------------------------------------- */
+
+/* The viewer re-projects the pre-filtered chain of a mirror-local environment every frame: a
+ * raster pass per (mip level, face) draws the environment's bounding mesh, back faces only, from
+ * the camera reflected across the mirror plane and looks the chain up in the direction of each
+ * fragment's position (src/main.cpp:523-604, shaders/mirrorLocal.vert:78-87,
+ * shaders/mirrorLocal.frag:17-19).  ibl_mirror_reproject_dev is that pass for one level as a
+ * per-texel computation, for a bounding mesh that is the axis-aligned box [box_min, box_max] of
+ * the environment's local space: d_src and d_out are w x w x 6 RGBA float32 cubes of the level;
+ * `camera` is the reflected camera position in that space (ibl_mirror_reflect_camera).  Texels
+ * whose ray misses the box get the pass's clear colour (0, 0, 0, 1).  The lookup is bilinear
+ * inside a face; bit parity with the hardware rasteriser and cube sampler is not claimed.  The
+ * caller loops over the levels like main.cpp:533. */
+int ibl_mirror_reproject_dev(const float* d_src, uint32_t w, const float* camera, const float* box_min,
+                             const float* box_max, float* d_out, void* stream);
+/* mirrorLocal.vert:81-82 (host arithmetic): transform is the environment's column-major 4x4
+ * world-to-local matrix, camera the world-space camera position; the local position is
+ * reflected across the plane z = -mirror_dist. */
+int ibl_mirror_reflect_camera(const float* transform, const float* camera, float mirror_dist, float* out);
+
 /* ---- host-buffer entry points -------------------------------------------- */
 
 int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* out);

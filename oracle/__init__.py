@@ -48,6 +48,10 @@ def lib():
         L.orc_pyramid_pad.restype = None
         L.orc_ggx_level_sampled.argtypes = [_f32p, _u32, _u32, _u32, _u32, _u32, ctypes.c_float, _u32, _u32, _f32p]
         L.orc_ggx_level_sampled.restype = ctypes.c_int
+        L.orc_mirror_reproject.argtypes = [_f32p, _u32, _f32p, _f32p, _f32p, _f32p]
+        L.orc_mirror_reproject.restype = None
+        L.orc_mirror_reflect_camera.argtypes = [_f32p, _f32p, ctypes.c_float, _f32p]
+        L.orc_mirror_reflect_camera.restype = None
         L.orc_lambertian.argtypes = [_f32p, _u32, _u32, _u32, _u32, _u32, _f32p, ctypes.c_int]
         L.orc_lambertian.restype = ctypes.c_int
         L.orc_ggx_mip_levels.argtypes = [_u32, _u32, _u32]
@@ -246,3 +250,22 @@ def png_filter_rows(rgba8):
     rows = np.zeros((h, 4 * w + 1), np.uint8)
     lib().orc_png_filter_rows(rgba8.reshape(-1), w, h, rows.reshape(-1))
     return rows
+
+
+def mirror_reflect_camera(transform, camera, mirror_dist):
+    """shaders/mirrorLocal.vert:81-82 on the CPU."""
+    out = np.zeros(3, np.float32)
+    lib().orc_mirror_reflect_camera(np.ascontiguousarray(transform, np.float32).reshape(16),
+                                    np.ascontiguousarray(camera, np.float32).reshape(3), float(mirror_dist), out)
+    return out
+
+
+def mirror_reproject(src, camera, box_min, box_max):
+    """CPU statement of the mirror-local re-projection of one cube level (ibl_mirror_oracle.c)."""
+    src = np.ascontiguousarray(src, np.float32)
+    w = src.shape[1]
+    out = np.zeros_like(src)
+    lib().orc_mirror_reproject(src.reshape(-1), w, np.ascontiguousarray(camera, np.float32).reshape(3),
+                               np.ascontiguousarray(box_min, np.float32).reshape(3),
+                               np.ascontiguousarray(box_max, np.float32).reshape(3), out.reshape(-1))
+    return out

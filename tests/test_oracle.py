@@ -310,3 +310,22 @@ def test_ggx_rejects_small_inputs(orc, w):
     env = np.ones((6, w, w, 4), np.float32)
     with pytest.raises(RuntimeError):
         orc.ggx_level(env, 4, 4, 1, 1)
+
+
+def test_mirror_statement_geometry(orc):
+    """The CPU statement of the mirror-local re-projection (parity unpinned: the reference holds
+    no output of this raster pass): identity from the centre of a cube-shaped box, clear colour
+    where the ray misses, and the reflected camera of shaders/mirrorLocal.vert:81-82."""
+    rng = np.random.default_rng(0)
+    src = rng.random((6, 16, 16, 4), dtype=np.float32)
+    out = orc.mirror_reproject(src, [0, 0, 0], [-1, -1, -1], [1, 1, 1])
+    assert np.abs(out - src).max() <= 2e-6
+    out = orc.mirror_reproject(src, [5, 0, 0], [-1, -1, -1], [1, 1, 1])
+    missed = (out == np.array([0, 0, 0, 1], np.float32)).all(axis=-1)
+    assert missed[0].all() and missed[2:].all() and not missed[1].all()     # only -X looks at the box
+    # moving the camera towards +x inside the box shifts what the +x face shows outwards
+    a = orc.mirror_reproject(src, [0.5, 0, 0], [-1, -1, -1], [1, 1, 1])
+    assert np.isfinite(a).all() and not np.array_equal(a, src)
+    t = np.eye(4, dtype=np.float32)
+    cam = orc.mirror_reflect_camera(t, [1.0, 2.0, 3.0], 0.5)
+    assert cam.tolist() == [1.0, 2.0, -4.0]

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "ibl_shard_indices": ([_int, _u32, _u32, _u32, _u32, _u32, _u32, _vp], _int),
     "ibl_shard_pack_dev": ([_int, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp], _int),
     "ibl_shard_unpack_dev": ([_int, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp], _int),
+    "ibl_mirror_reproject_dev": ([_vp, _u32, _vp, _vp, _vp, _vp, _vp], _int),
+    "ibl_mirror_reflect_camera": ([_vp, _vp, ctypes.c_float, _vp], _int),
     "ibl_brdf_lut_dev": ([_u32, _u32, _u32, _u64, _int, _u32, _u32, _vp, _vp], _int),
     "ibl_rgbe_decode_dev": ([_vp, _vp, _u32, _vp], _int),
     "ibl_rgbe_encode_dev": ([_vp, _vp, _u32, _vp], _int),
@@ -230,6 +232,25 @@ class Ibl:
             out = self.torch.zeros((6, out_w, out_w, 4), dtype=self.torch.float32, device=self.device)
         self._check(self.lib.ibl_ggx_level_shard_dev(_ptr(env), w, h, out_w, out_w, mip, mips, shard, n_shards,
                                                      _ptr(out), self._stream(stream)))
+        return out
+
+    # -- mirror-local re-projection ----------------------------------------------------------
+    def mirror_reflect_camera(self, transform, camera, mirror_dist):
+        t = np.ascontiguousarray(transform, np.float32).reshape(16)
+        c = np.ascontiguousarray(camera, np.float32).reshape(3)
+        out = np.zeros(3, np.float32)
+        self._check(self.lib.ibl_mirror_reflect_camera(t.ctypes.data, c.ctypes.data, float(mirror_dist), out.ctypes.data))
+        return out
+
+    def mirror_reproject(self, src, camera, box_min, box_max, out=None, stream=None):
+        """One level of a mirror-local environment's chain, re-projected through the reflected camera."""
+        w, h = self._env(src)
+        assert w == h
+        if out is None:
+            out = self.torch.empty_like(src)
+        c, lo, hi = (np.ascontiguousarray(v, np.float32).reshape(3) for v in (camera, box_min, box_max))
+        self._check(self.lib.ibl_mirror_reproject_dev(_ptr(src), w, c.ctypes.data, lo.ctypes.data, hi.ctypes.data, _ptr(out),
+                                                      self._stream(stream)))
         return out
 
     # -- shards: the exchange step between GPUs ----------------------------------------------

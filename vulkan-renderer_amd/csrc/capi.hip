@@ -825,6 +825,38 @@ int ibl_texel_directions_dev(uint32_t w, uint32_t h, int normalized, float* d_ou
     return IBL_OK;
 }
 
+// ---- mirror-local re-projection ---------------------------------------------------
+
+int ibl_mirror_reflect_camera(const float* transform, const float* camera, float mirror_dist, float* out) {
+    if (!transform || !camera || !out) return fail(IBL_EINVAL, "mirror_reflect_camera: null pointer");
+    float p[3];
+    for (int r = 0; r < 3; r++) {
+        volatile float v = transform[r] * camera[0];
+        v = v + transform[4 + r] * camera[1];
+        v = v + transform[8 + r] * camera[2];
+        v = v + transform[12 + r];
+        p[r] = v;
+    }
+    out[0] = p[0];
+    out[1] = p[1];
+    out[2] = -(p[2] + mirror_dist) - mirror_dist;
+    return IBL_OK;
+}
+
+int ibl_mirror_reproject_dev(const float* d_src, uint32_t w, const float* camera, const float* box_min,
+                             const float* box_max, float* d_out, void* stream) {
+    if (int rc = check_ready()) return rc;
+    if (!d_src || !d_out || !camera || !box_min || !box_max) return fail(IBL_EINVAL, "mirror_reproject: null pointer");
+    if (d_src == d_out) return fail(IBL_EINVAL, "mirror_reproject: source and destination must differ");
+    if (int rc = check_cube(w, w, "mirror_reproject cube")) return rc;
+    for (int k = 0; k < 3; k++) {
+        if (!(box_min[k] < box_max[k])) return fail(IBL_EINVAL, "mirror_reproject: empty bounding box on axis %d", k);
+        if (!(camera[k] == camera[k])) return fail(IBL_EINVAL, "mirror_reproject: camera position is not a number");
+    }
+    HIP_TRY(ibl::mirror_reproject_launch(d_src, w, camera, box_min, box_max, d_out, pick(stream)));
+    return IBL_OK;
+}
+
 // ---- host-buffer entry points ---------------------------------------------------
 
 namespace {

@@ -137,6 +137,10 @@ hipError_t shard_pack_launch(const ShardMap& m, uint32_t shard, uint32_t elem_by
 hipError_t shard_unpack_launch(const ShardMap& m, uint32_t elem_bytes, const void* d_packed_all, void* d_full,
                                hipStream_t stream);
 
+// Mirror-local re-projection of one cube level (mirror_reproject.hip).
+hipError_t mirror_reproject_launch(const float* d_src, uint32_t w, const float cam[3], const float bmin[3],
+                                   const float bmax[3], float* d_out, hipStream_t stream);
+
 // Sampled GGX mode (ggx_sampled.hip): box pyramid of the environment and the level kernel.
 uint32_t pyramid_levels(uint32_t w);
 uint64_t pyramid_offset(uint32_t w, uint32_t level);     // in float4 texels
