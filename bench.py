@@ -45,6 +45,10 @@ FLOP_PER_LAMBERTIAN_PAIR = 12       # pair by pair: dot 5, max 1, 3 FMA 6
 # add and 12 packed FMAs of 2 x 2 flop (49).
 LAMB_FLOP_PER_LANE_RECORD = 11
 LAMB_FLOP_PER_LANE_PATTERN = 49
+# ls_pairs (the default: clamped cosine split into even and odd halves) per lane and record, as
+# issued: 1 multiply, 6 FMAs that form the four cosines (12), 8 adds of the Walsh-Hadamard
+# butterfly, 6 packed FMAs of 2 x 2 flop (24): 45.  No per-pattern part.
+LAMB_SPLIT_FLOP_PER_LANE_RECORD = 45
 # ggx_oct_pairs per lane, record and pattern: cosine 5, u/t/d 5, rcp + sqrt 2, two clamped ops 2,
 # three multiplies 3, the weight sum's FMA 2 (19) and 12 packed FMAs (48).
 GGX_FLOP_PER_LANE_PATTERN = 67
@@ -108,11 +112,16 @@ class Workload:
             ibl.lambertian_shard(self.env, self.out_w, rank, world, out=self.out)
             c = ibl.last_counts()
             ibl.set_counting(False)
-            if c["wave_records"]:
+            self.split = ibl.get_tuning("lamb_split") != 0
+            self.exact_octets = ibl.last_exact_octets() if self.split else None
+            if c["wave_records"] and self.split:
+                self.executed_flop_per_launch = 64.0 * LAMB_SPLIT_FLOP_PER_LANE_RECORD * c["wave_records"]
+                self.patterns_per_record = None
+            elif c["wave_records"]:
                 self.executed_flop_per_launch = 64.0 * (LAMB_FLOP_PER_LANE_RECORD * c["wave_records"]
                                                         + LAMB_FLOP_PER_LANE_PATTERN * c["wave_patterns"])
                 self.patterns_per_record = c["wave_patterns"] / c["wave_records"]
-            self.kernel = "lambertian_oct_pairs"
+            self.kernel = "ls_pairs" if self.split else "lambertian_oct_pairs"
             self.desc = ("C%s: Lambertian irradiance %dx%d/face -> %dx%d/face, all (output, input) texel pairs"
                          % (name[1], self.in_w, self.in_w, self.out_w, self.out_w))
             self.bytes_per_launch = 24 * self.n_in + 16 * self.count
@@ -446,6 +455,9 @@ def main():
         }
         if getattr(wl, "patterns_per_record", None):
             line["roofline"]["sign_patterns_per_record"] = round(wl.patterns_per_record, 3)
+        if getattr(wl, "exact_octets", None) is not None:
+            # output octets whose even and odd halves cancel too far and were redone with exact weights
+            line["roofline"]["exact_weight_octets"] = wl.exact_octets
         try:   # measured HBM traffic of the same launch, from the committed rocprofv3 PMC passes
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tr = json.load(f).get(wl.name)
@@ -456,6 +468,25 @@ def main():
             pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+
+    # The same workload on the exact-weights octet kernel (every pair weighted as the reference
+    # weights it; the default falls back to it octet by octet where its split cancels too far).
+    if args.workload == "c4" and not args.no_extras and getattr(wl, "split", False):
+        ibl.set_tuning("lamb_split", 0)
+        try:
+            wx = Workload("c4", args, ibl, rank, world, dist)
+            ex_elapsed, ex_kernel_ms = run_timed(wx, 3, 1, torch, dist, world, ibl.device)
+            if line is not None:
+                line["c4_exact_weights_ms_per_step"] = round(ex_elapsed / 3 * 1e3, 4)
+                line["c4_exact_weights_kernel"] = wx.kernel
+                line["c4_exact_weights_kernel_ms"] = round(ex_kernel_ms, 4)
+                if wx.executed_flop_per_launch and ex_kernel_ms > 0:
+                    tf = wx.executed_flop_per_launch / (ex_kernel_ms * 1e-3) / 1e12
+                    line["c4_exact_weights_executed_tflops"] = round(tf, 2)
+                    line["c4_exact_weights_frac_of_fp32_peak"] = round(tf / FP32_VECTOR_PEAK_TFLOPS, 4)
+            del wx
+        finally:
+            ibl.set_tuning("lamb_split", 1)
 
     # The rest of the bake: the GGX chains of configurations 3 and 5, every rank taking part.
     if args.workload == "c4" and not args.no_extras:

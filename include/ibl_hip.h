@@ -299,6 +299,8 @@ int ibl_set_kernel_mode(int general_only);
  * library's own, the tools under tools/ use them).  They change speed only, except
  * the slice counts, which fix the order of the sums and with it the last bits. */
 int ibl_set_tuning(const char* name, double value);
+/* The current value of a knob ("general_only" reads back ibl_set_kernel_mode). */
+int ibl_get_tuning(const char* name, double* value);
 
 /* When enabled, every *_dev call brackets its dominant kernel with HIP events on
  * the stream it was launched on. */
@@ -317,6 +319,14 @@ int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted)
  * With the kernels' instruction counts per record and per pattern this prices the arithmetic
  * actually executed.  0 for the general kernels. */
 int ibl_last_wave_work(uint64_t* wave_records, uint64_t* wave_patterns);
+/* Mirror-octet Lambertian, counting on.  The integral (cube.cpp:95-129) is evaluated with the
+ * clamped cosine split into its even and odd halves, a quarter of the arithmetic; where a texel
+ * comes out as the small difference of much larger halves (a texel in deep shadow of a very
+ * bright light: cancellation above the knob "lamb_split_limit", 8), its octet (the texel and
+ * its 7 mirror images) is recomputed with the reference's own per-pair weights.  This returns
+ * how many octets of the last call were.  ("lamb_split" 0 computes everything with those
+ * weights.) */
+int ibl_last_exact_octets(uint64_t* octets);
 
 #ifdef __cplusplus
 }

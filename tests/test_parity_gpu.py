@@ -36,6 +36,19 @@ def kernel_mode(request, ibl):
     ibl.set_kernel_mode(False)
 
 
+@pytest.fixture(params=["split", "exact", "general"])
+def lamb_mode(request, ibl):
+    """The three implementations of the Lambertian integral: mirror octets with the clamped cosine
+    split into its even and odd halves (the default; blocks it cannot hold to ~1e-6 are redone with
+    exact weights), mirror octets with the reference's per-pair weights throughout
+    (ibl_set_tuning("lamb_split", 0)), and the general kernel."""
+    ibl.set_kernel_mode(request.param == "general")
+    ibl.set_tuning("lamb_split", 0 if request.param == "exact" else 1)
+    yield request.param
+    ibl.set_kernel_mode(False)
+    ibl.set_tuning("lamb_split", 1)
+
+
 def _dev(ibl, arr):
     return ibl.torch.from_numpy(np.ascontiguousarray(arr)).to(ibl.device)
 
@@ -190,7 +203,7 @@ def test_downscale_rejects_bad_factor(ibl, orc):
 # ---- Lambertian --------------------------------------------------------------------------
 
 @pytest.mark.parametrize("w,out", [(16, 8), (64, 32), (32, 5), (128, 16), (24, 6), (30, 10), (17, 3)])
-def test_lambertian_parity(ibl, orc, w, out, kernel_mode):
+def test_lambertian_parity(ibl, orc, w, out, lamb_mode):
     env, env_d = _env(ibl, orc, w)
     got = ibl.lambertian(env_d, out).cpu().numpy()
     _check_cube(orc, got, orc.lambertian(env, out))
@@ -204,7 +217,7 @@ def test_lambertian_config1_host_api(ibl, orc):
 
 
 @pytest.mark.parametrize("kind", ["const", "single"])
-def test_lambertian_special_environments(ibl, orc, kind, kernel_mode):
+def test_lambertian_special_environments(ibl, orc, kind, lamb_mode):
     env, env_d = _env(ibl, orc, 32, kind=kind)
     got = ibl.lambertian(env_d, 16).cpu().numpy()
     want = orc.lambertian(env, 16)
@@ -217,7 +230,55 @@ def test_lambertian_special_environments(ibl, orc, kind, kernel_mode):
     _check_cube(orc, got, want, tight=2e-5 if kind == "single" else 5e-6)
 
 
-def test_lambertian_large_input_subset(ibl, orc, kernel_mode):
+def test_lambertian_split_falls_back_where_it_cancels(ibl, orc):
+    """The default kernel splits the clamped cosine into an even and an odd half.  Texels that see
+    far less light than their mirror images (deep shadow of a very bright light) are the small
+    difference of the halves; their octets must be found and redone with the reference's own
+    weights -- and which ones are must not depend on how the cube is cut into calls."""
+    env, _ = _env(ibl, orc, 64)
+    env[0, 20:24, 30:34, :3] = np.float32(1.5e3)             # a small bright light on +x: up to ~10x the sky's irradiance
+    env_d = _dev(ibl, env)
+    want = orc.lambertian(env, 32)
+    ibl.set_counting(True)
+    try:
+        got = ibl.lambertian(env_d, 32)
+        redone = ibl.last_exact_octets()
+        n_oct = 6 * 32 * 32 // 8
+        assert 0 < redone < n_oct, redone                    # octets with a member in the light's deep shadow
+        _check_cube(orc, got.cpu().numpy(), want, label="bright light, %d of %d octets redone" % (redone, n_oct))
+        # a much brighter light on a dim sky shadows a member of every octet: everything is redone
+        dim = env * np.float32(0.01)
+        dim[0, 20:24, 30:34, :3] = np.float32(3.0e4)
+        got_dim = ibl.lambertian(_dev(ibl, dim), 32)
+        assert ibl.last_exact_octets() == n_oct
+        _check_cube(orc, got_dim.cpu().numpy(), orc.lambertian(dim, 32), label="very bright light on a dim sky")
+        # the ordinary synthetic environment needs none
+        plain, plain_d = _env(ibl, orc, 64)
+        ibl.lambertian(plain_d, 32)
+        assert ibl.last_exact_octets() == 0
+    finally:
+        ibl.set_counting(False)
+    # ranges and shards give the same bits, fallback octets included
+    n_out = 6 * 32 * 32
+    parts = ibl.torch.zeros_like(got)
+    cuts = [0, 77, n_out // 3, n_out - 513, n_out]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ibl.lambertian(env_d, 32, out_begin=a, out_count=b - a, out=parts)
+    assert ibl.torch.equal(got, parts)
+    acc = ibl.torch.zeros_like(got)
+    for sh in range(3):
+        acc += ibl.lambertian_shard(env_d, 32, sh, 3)
+    assert ibl.torch.equal(acc, got)
+    # exact weights everywhere agree with the mixture to the accuracy of the split
+    ibl.set_tuning("lamb_split", 0)
+    try:
+        exact = ibl.lambertian(env_d, 32).cpu().numpy()
+    finally:
+        ibl.set_tuning("lamb_split", 1)
+    assert rel_err(got.cpu().numpy().reshape(-1, 4), exact.reshape(-1, 4)).max() < 5e-6
+
+
+def test_lambertian_large_input_subset(ibl, orc, lamb_mode):
     """1024x1024/face input (the headline Lambertian configuration's input), 256 of its 128x128/face
     output texels against the oracle; the full output is covered by
     test_lambertian_full_size_properties."""
@@ -232,7 +293,7 @@ def test_lambertian_large_input_subset(ibl, orc, kernel_mode):
     assert (flat[:begin] == 0).all() and (flat[begin + 256:] == 0).all()
 
 
-def test_lambertian_full_size_properties(ibl, orc, kernel_mode):
+def test_lambertian_full_size_properties(ibl, orc, lamb_mode):
     """The headline Lambertian configuration (1024x1024/face -> 128x128/face) at full size through size-independent properties:
     a sharded bake equals the unsharded one bit for bit, a constant environment
     comes back as (quadrature-exact) that constant, and the operator is linear."""

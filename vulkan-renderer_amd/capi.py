@@ -33,6 +33,8 @@ _SIGNATURES = {
     "ibl_initialized_devices": ([], _int),
     "ibl_set_kernel_mode": ([_int], _int),
     "ibl_set_tuning": ([ctypes.c_char_p, ctypes.c_double], _int),
+    "ibl_get_tuning": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)], _int),
+    "ibl_last_exact_octets": ([ctypes.POINTER(_u64)], _int),
     "ibl_shutdown": ([], _int),
     "ibl_last_error": ([], ctypes.c_char_p),
     "ibl_device_count": ([], _int),
@@ -356,6 +358,16 @@ class Ibl:
 
     def set_tuning(self, name, value):
         self._check(self.lib.ibl_set_tuning(name.encode(), float(value)))
+
+    def get_tuning(self, name):
+        v = ctypes.c_double()
+        self._check(self.lib.ibl_get_tuning(name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def last_exact_octets(self):
+        v = _u64()
+        self._check(self.lib.ibl_last_exact_octets(ctypes.byref(v)))
+        return v.value
 
     def set_timing(self, on):
         self._check(self.lib.ibl_set_timing(int(bool(on))))

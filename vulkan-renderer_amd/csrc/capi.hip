@@ -49,7 +49,7 @@ struct State {
     bool timing = false, counting = false, timed_valid = false;
     Buffer a, b, pn, partial, counts, stage_in, stage_out, units;
     void* static_scratch = nullptr; // this device's copy of the file-scope scratch array (ibl_lambertian_static_dev)
-    uint64_t last_counts[5] = {0, 0, 0, 0, 0};   // patch tests, texel tests, accepted, wave-records, wave-patterns
+    uint64_t last_counts[6] = {0, 0, 0, 0, 0, 0};   // patch tests, texel tests, accepted, wave-records, wave-patterns, exact blocks
     int counts_pending = 0;          // 1: a GGX call's counters wait on the device, 2: a Lambertian call's
 };
 
@@ -116,6 +116,7 @@ void read_tuning_once() {
     if (const char* e = getenv("IBL_LAMB_OCT_SLICES")) g_tuning.lamb_oct_slices = (uint32_t)atoi(e);
     if (const char* e = getenv("IBL_LAMB_OCT_RUN")) g_tuning.lamb_oct_run = atoi(e);
     if (const char* e = getenv("IBL_LAMB_OCT_AFFINE")) g_tuning.lamb_oct_affine = atoi(e);
+    if (const char* e = getenv("IBL_LAMB_SPLIT")) g_tuning.lamb_split = atoi(e);
     if (const char* e = getenv("IBL_GGX_WAVES")) g_tuning.ggx_waves = atof(e);
     if (const char* e = getenv("IBL_GGX_XCD_SLICES")) g_tuning.ggx_xcd_slices = atoi(e);
     if (const char* e = getenv("IBL_GGX_CORE")) g_tuning.ggx_core = (float)atof(e);
@@ -275,11 +276,31 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "lamb_oct_slices")) g_tuning.lamb_oct_slices = (uint32_t)value;
     else if (!strcmp(name, "lamb_oct_run")) g_tuning.lamb_oct_run = (int)value;
     else if (!strcmp(name, "lamb_oct_affine")) g_tuning.lamb_oct_affine = (int)value;
+    else if (!strcmp(name, "lamb_split")) g_tuning.lamb_split = (int)value;
+    else if (!strcmp(name, "lamb_split_limit")) g_tuning.lamb_split_limit = (float)value;
     else if (!strcmp(name, "ggx_waves")) g_tuning.ggx_waves = value;
     else if (!strcmp(name, "ggx_xcd_slices")) g_tuning.ggx_xcd_slices = (int)value;
     else if (!strcmp(name, "ggx_core")) g_tuning.ggx_core = (float)value;
     else if (!strcmp(name, "bake_rehearse_shards")) g_tuning.bake_rehearse_shards = (int)value;
     else return fail(IBL_EINVAL, "set_tuning: unknown knob %s", name);
+    return IBL_OK;
+}
+
+int ibl_get_tuning(const char* name, double* value) {
+    read_tuning_once();
+    if (!name || !value) return fail(IBL_EINVAL, "get_tuning: null pointer");
+    if (!strcmp(name, "lamb_p")) *value = g_tuning.lamb_p;
+    else if (!strcmp(name, "lamb_oct_slices")) *value = g_tuning.lamb_oct_slices;
+    else if (!strcmp(name, "lamb_oct_run")) *value = g_tuning.lamb_oct_run;
+    else if (!strcmp(name, "lamb_oct_affine")) *value = g_tuning.lamb_oct_affine;
+    else if (!strcmp(name, "lamb_split")) *value = g_tuning.lamb_split;
+    else if (!strcmp(name, "lamb_split_limit")) *value = g_tuning.lamb_split_limit;
+    else if (!strcmp(name, "ggx_waves")) *value = g_tuning.ggx_waves;
+    else if (!strcmp(name, "ggx_xcd_slices")) *value = g_tuning.ggx_xcd_slices;
+    else if (!strcmp(name, "ggx_core")) *value = g_tuning.ggx_core;
+    else if (!strcmp(name, "bake_rehearse_shards")) *value = g_tuning.bake_rehearse_shards;
+    else if (!strcmp(name, "general_only")) *value = g_tuning.no_octets ? 1.0 : 0.0;
+    else return fail(IBL_EINVAL, "get_tuning: unknown knob %s", name);
     return IBL_OK;
 }
 
@@ -333,12 +354,13 @@ int ibl_last_kernel_ms(float* ms) {
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
     if (int rc = check_ready()) return rc;
     if (S->counts_pending) {
-        unsigned long long h[5];
+        unsigned long long h[6];
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, S->counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
         if (S->counts_pending == 1) { S->last_counts[1] = h[1]; S->last_counts[2] = h[2]; }   // GGX: texel tests
         S->last_counts[3] = h[3];
         S->last_counts[4] = h[4];
+        S->last_counts[5] = h[5];
         S->counts_pending = 0;
     }
     if (patch_tests) *patch_tests = S->last_counts[0];
@@ -354,6 +376,12 @@ int ibl_last_wave_work(uint64_t* wave_records, uint64_t* wave_patterns) {
     return IBL_OK;
 }
 
+int ibl_last_exact_octets(uint64_t* octets) {
+    if (int rc = ibl_last_counts(nullptr, nullptr, nullptr)) return rc;
+    if (octets) *octets = S->last_counts[5];
+    return IBL_OK;
+}
+
 // ---- device-resident entry points ---------------------------------------------
 
 int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
@@ -366,7 +394,7 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
     if (int rc = check_range(out_begin, out_count, n_out, "lambertian")) return rc;
     const uint32_t n_in = in_w * in_h * 6;
     S->last_counts[0] = 0;
-    S->last_counts[3] = S->last_counts[4] = 0;
+    S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
     S->last_counts[1] = (uint64_t)out_count * n_in;
     S->last_counts[2] = 0;
     S->counts_pending = 0;
@@ -423,7 +451,7 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
     const uint32_t begin = shard * per < n_oct ? shard * per : n_oct;
     const uint32_t count = per < n_oct - begin ? per : n_oct - begin;
     S->last_counts[0] = 0;
-    S->last_counts[3] = S->last_counts[4] = 0;
+    S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
     S->last_counts[1] = (uint64_t)count * 8 * in_w * in_h * 6;
     S->last_counts[2] = 0;
     S->counts_pending = 0;
@@ -455,6 +483,7 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
     ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, ibl::lambertian_oct_blocks_total(out_size));
     // The run form stores an eighth of the partial sums and gives the same bits as the slice form.
     pl.run = pl.n_slices > 1;
+    pl.split = false;      // exact weights in one pass: the scratch array has no room for both
     pl.partial_bytes = ibl::lambertian_oct_partial_bytes(pl);
     const size_t rec_bytes = (pl.rec_bytes + 255) & ~(size_t)255;
     if (rec_bytes + pl.partial_bytes > STATIC_SCRATCH_BYTES)
@@ -462,7 +491,7 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
                     "static array holds %zu (e.g. 512 -> 32, 256 -> 32, 128 -> 64 fit); use ibl_lambertian_dev",
                     in_w, in_w, out_size, out_size, rec_bytes + pl.partial_bytes, STATIC_SCRATCH_BYTES);
     S->last_counts[0] = 0;
-    S->last_counts[3] = S->last_counts[4] = 0;
+    S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
     S->last_counts[1] = (uint64_t)n_out * in_w * in_h * 6;
     S->last_counts[2] = 0;
     S->counts_pending = 0;
@@ -529,7 +558,7 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
     if (int rc = check_range(out_begin, out_count, n_out, "ggx")) return rc;
     const uint32_t n_patches = 6 * (in_w / patch) * (in_h / patch);
     S->last_counts[0] = (uint64_t)out_count * n_patches;
-    S->last_counts[3] = S->last_counts[4] = 0;
+    S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
     S->last_counts[1] = S->last_counts[2] = 0;
     S->counts_pending = 0;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
@@ -586,7 +615,7 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
     const uint32_t n_units = (n_oct + 63) / 64;
     const uint32_t mine = shard < n_units ? (n_units - shard + n_shards - 1) / n_shards : 0;
     S->last_counts[0] = (uint64_t)mine * 64 * 8 * n_patches;
-    S->last_counts[3] = S->last_counts[4] = 0;
+    S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
     S->last_counts[1] = S->last_counts[2] = 0;
     S->counts_pending = 0;
     if (mine == 0) { S->timed_valid = false; return IBL_OK; }
@@ -730,7 +759,7 @@ int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, ui
         return fail(IBL_EINVAL, "brdf_lut: unknown jitter mode %d", jitter_mode);
     if (int rc = check_range(cell_begin, cell_count, (uint64_t)n_rough * n_cos, "brdf_lut")) return rc;
     S->last_counts[0] = 0;
-    S->last_counts[3] = S->last_counts[4] = 0;
+    S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
     S->last_counts[1] = (uint64_t)cell_count * samples_sqrt * samples_sqrt;
     S->last_counts[2] = 0;
     S->counts_pending = 0;
@@ -805,7 +834,7 @@ int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t ou
     if (!(lod_bias > -64.0f && lod_bias < 64.0f)) return fail(IBL_EINVAL, "ggx_sampled: lod bias out of range");
     if (int rc = check_range(out_begin, out_count, (uint64_t)out_w * out_w * 6, "ggx_sampled")) return rc;
     S->last_counts[0] = 0;
-    S->last_counts[3] = S->last_counts[4] = 0;
+    S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
     S->last_counts[1] = S->last_counts[2] = (uint64_t)out_count * n_samples;
     S->counts_pending = 0;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }

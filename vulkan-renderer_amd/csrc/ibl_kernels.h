@@ -20,6 +20,8 @@ struct Tuning {
     int ggx_xcd_slices = -1;       // octet GGX kernel: 1 / 0 force / forbid dealing runs to the XCDs (-1: automatic)
     int bake_rehearse_shards = 0;  // ibl_bake_*: > 1 makes one device play that many shards in turn (tests)
     float ggx_core = 2.0f;         // multiple of alpha^2 below which the reference's own denominator is repeated
+    int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
+    float lamb_split_limit = 8.0f; // ... blocks whose texels cancel by more than this factor are redone with exact weights
 };
 Tuning& tuning();
 
@@ -47,11 +49,20 @@ struct LambertianOctPlan {
     uint32_t n_slices;
     uint32_t n_runs;       // runs of 8 consecutive slices: the first stage of the summation order
     bool run;              // a workgroup walks a whole run (large calls) or one slice (small calls)
+    bool split;            // the split form runs first, the exact kernels only on the blocks it marks
     uint32_t out_blocks;   // 256-octet output blocks the call covers
     size_t partial_bytes;  // [run][24][out_blocks*256] double + (slice form) [slice][24][out_blocks*256] float
     size_t rec_bytes;      // 7 float4 per input octet
 };
 size_t lambertian_oct_partial_bytes(const LambertianOctPlan& pl);
+// lambertian_split.hip: the workspace header (marks of the output blocks, first moment and its parts)
+// and the sums of the split form; the pass itself.
+size_t lambertian_split_header_bytes(uint32_t n_oct_in, uint32_t out_blocks);
+size_t lambertian_split_sums_bytes(const LambertianOctPlan& pl);
+hipError_t lambertian_split_launch(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
+                                   const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
+                                   uint32_t out_begin, uint32_t out_count, float* d_out, void* d_rec, void* d_work,
+                                   unsigned long long* d_counts, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 uint32_t lambertian_oct_blocks_total(uint32_t out_size);
 uint32_t lambertian_oct_tile_edge(uint32_t out_size);
 constexpr uint32_t LAMBERTIAN_OCT_BLOCK = 256;   // output octets per workgroup

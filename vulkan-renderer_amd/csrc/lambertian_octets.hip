@@ -52,10 +52,16 @@ bool cube_is_mirror_exact(uint32_t w) {
     return true;
 }
 
+// any_flag (here and below: flags, one per output octet of the call, then one per 256-octet
+// block): when given, only the blocks that hold a marked octet are worked on, and only the marked
+// octets are stored -- the second pass after lambertian_split.hip; nothing at all happens when no
+// octet is marked.
 __global__ __launch_bounds__(256) void lambertian_oct_prep(const float4* __restrict__ env, uint32_t w, uint32_t h,
-                                                            uint32_t n_oct, float4* __restrict__ rec) {
+                                                            uint32_t n_oct, const uint32_t* __restrict__ any_flag,
+                                                            float4* __restrict__ rec) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_oct) return;
+    if (any_flag && *any_flag == 0u) return;
     const uint32_t hw = w / 2, hh = h / 2;
     uint32_t axis = k / (hw * hh);
     uint32_t rem = k - axis * (hw * hh);
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(OCT_THREADS, RUN ? OCT_MIN_WAVES_RUN : OCT_MIN_WAVE
     const float4* __restrict__ rec, uint32_t n_oct_in, uint32_t slice_len, uint32_t n_slices,
     uint32_t out_size, const uint32_t* __restrict__ block_list, uint32_t oct_begin, uint32_t oct_end,
     uint32_t out_blocks, uint32_t xcd_affine, uint32_t out_begin, uint32_t out_count,
-    void* __restrict__ partial_out, unsigned long long* __restrict__ counts) {
+    const uint32_t* __restrict__ flags, void* __restrict__ partial_out, unsigned long long* __restrict__ counts) {
     __shared__ float4 s_rec[2][OCT_TILE * OCT_REC];
 
     const uint32_t tid = threadIdx.x;
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(OCT_THREADS, RUN ? OCT_MIN_WAVES_RUN : OCT_MIN_WAVE
         slot = blockIdx.x / out_blocks;
         ob = blockIdx.x % out_blocks;
     }
+    if (flags && flags[out_blocks * OCT_THREADS + ob] == 0u) return;
     const uint32_t sl0 = RUN ? slot * OCT_RUN : slot;
     const uint32_t sl1 = RUN ? min(n_slices, sl0 + OCT_RUN) : sl0 + 1;
 
@@ -302,10 +309,12 @@ __global__ __launch_bounds__(OCT_THREADS, RUN ? OCT_MIN_WAVES_RUN : OCT_MIN_WAVE
 // The run sums B_b from the slice sums S_s (RUN = false calls only): one thread per
 // (output octet, member, run).
 __global__ __launch_bounds__(256) void lambertian_oct_reduce(const float* __restrict__ partial, uint32_t n_slices,
-                                                              uint32_t oct_local, double* __restrict__ reduced) {
+                                                              uint32_t oct_local, const uint32_t* __restrict__ flags,
+                                                              double* __restrict__ reduced) {
     const uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = blockIdx.y, g = blockIdx.z;
     if (lo >= oct_local) return;
+    if (flags && flags[lo] == 0u) return;
     const uint32_t s0 = g * OCT_RUN, s1 = min(n_slices, s0 + OCT_RUN);
     double v[3] = {0.0, 0.0, 0.0};
     for (uint32_t sl = s0; sl < s1; sl++) {
@@ -321,11 +330,13 @@ __global__ __launch_bounds__(256) void lambertian_oct_final(const double* __rest
                                                              uint32_t out_size, const uint32_t* __restrict__ block_list,
                                                              uint32_t oct_begin, uint32_t oct_end, uint32_t oct_local,
                                                              uint32_t out_begin, uint32_t out_count, double scale,
+                                                             const uint32_t* __restrict__ flags,
                                                              float4* __restrict__ out) {
     const uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = blockIdx.y;
     if (lo >= oct_local) return;
     const uint32_t ob = lo / OCT_THREADS;
+    if (flags && flags[lo] == 0u) return;
     const uint32_t oo = (block_list ? block_list[ob] * OCT_THREADS : oct_begin + ob * OCT_THREADS) + lo % OCT_THREADS;
     if (oo >= oct_end) return;
     const uint32_t hw = out_size / 2;
@@ -406,10 +417,15 @@ hipError_t octet_units_strided_launch(uint32_t first, uint32_t stride, uint32_t 
     return hipGetLastError();
 }
 
-// [run][24][octets] double, preceded in the slice form by [slice][24][octets] float
+// [run][24][octets] double, followed in the slice form by [slice][24][octets] float.  With the
+// split form in front (lambertian_split.hip) the workspace starts with its header and holds
+// whichever of the two passes' sums is larger.
 size_t lambertian_oct_partial_bytes(const LambertianOctPlan& pl) {
     const size_t sums = (size_t)24 * pl.out_blocks * OCT_THREADS;
-    return sums * sizeof(double) * pl.n_runs + (pl.run ? 0 : sums * sizeof(float) * pl.n_slices);
+    const size_t exact = sums * sizeof(double) * pl.n_runs + (pl.run ? 0 : sums * sizeof(float) * pl.n_slices);
+    if (!pl.split) return exact;
+    const size_t fast = lambertian_split_sums_bytes(pl);
+    return lambertian_split_header_bytes(pl.n_oct_in, pl.out_blocks) + (fast > exact ? fast : exact);
 }
 
 LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks) {
@@ -430,6 +446,7 @@ LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks) {
     pl.n_runs = (pl.n_slices + OCT_RUN - 1) / OCT_RUN;
     pl.out_blocks = out_blocks;
     pl.run = tuning().lamb_oct_run > 0 && pl.n_slices > 1;
+    pl.split = tuning().lamb_split != 0;
     pl.partial_bytes = lambertian_oct_partial_bytes(pl);
     pl.rec_bytes = (size_t)pl.n_oct_in * OCT_REC * sizeof(float4);
     return pl;
@@ -440,7 +457,21 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
                                  uint32_t out_begin, uint32_t out_count,
                                  float* d_out, void* d_rec, double* d_partial, unsigned long long* d_counts,
                                  hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    // Split form first: every block at a quarter of the arithmetic, then this file's kernels only
+    // for the blocks it marked (none for an environment of ordinary contrast: the launches below
+    // then return at once).
+    const uint32_t* d_flags = nullptr;
+    if (pl.split) {
+        if (hipError_t e = lambertian_split_launch(pl, d_env, in_w, out_size, d_block_list, oct_begin, oct_end, out_begin,
+                                                   out_count, d_out, d_rec, d_partial, d_counts, stream, ev0, ev1);
+            e != hipSuccess) return e;
+        d_flags = (const uint32_t*)d_partial;
+        d_partial = (double*)((char*)d_partial + lambertian_split_header_bytes(pl.n_oct_in, pl.out_blocks));
+        ev0 = ev1 = nullptr;
+    }
+    const uint32_t oct_local_all = pl.out_blocks * OCT_THREADS;
     lambertian_oct_prep<<<(pl.n_oct_in + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, in_w, pl.n_oct_in,
+                                                                       d_flags ? d_flags + oct_local_all + pl.out_blocks : nullptr,
                                                                        (float4*)d_rec);
     const uint32_t oct_local = pl.out_blocks * OCT_THREADS;
     const uint32_t n_slots = pl.run ? pl.n_runs : pl.n_slices;
@@ -450,20 +481,22 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
     // workspace: the run sums first, then (slice form) the slice sums
     double* d_runs = d_partial;
     float* d_slices = (float*)(d_partial + (size_t)pl.n_runs * 24 * oct_local);
+    // (the second pass does not count: the counters price the kernel that does the work)
+    unsigned long long* counts = pl.split ? nullptr : d_counts;
     auto go = [&](auto kernel, void* d_store) {
         kernel<<<grid, OCT_THREADS, 0, stream>>>(
             (const float4*)d_rec, pl.n_oct_in, pl.slice_len, pl.n_slices, out_size, d_block_list, oct_begin, oct_end,
-            pl.out_blocks, affine, out_begin, out_count, d_store, d_counts);
+            pl.out_blocks, affine, out_begin, out_count, d_flags, d_store, counts);
     };
-    if (pl.run) { if (d_counts) go(lambertian_oct_pairs<true, true>, d_runs); else go(lambertian_oct_pairs<true, false>, d_runs); }
-    else        { if (d_counts) go(lambertian_oct_pairs<false, true>, d_slices); else go(lambertian_oct_pairs<false, false>, d_slices); }
+    if (pl.run) { if (counts) go(lambertian_oct_pairs<true, true>, d_runs); else go(lambertian_oct_pairs<true, false>, d_runs); }
+    else        { if (counts) go(lambertian_oct_pairs<false, true>, d_slices); else go(lambertian_oct_pairs<false, false>, d_slices); }
     if (ev1) (void)hipEventRecord(ev1, stream);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);
     if (!pl.run)
         lambertian_oct_reduce<<<dim3((oct_local + 255) / 256, 8, pl.n_runs), 256, 0, stream>>>(
-            (const float*)d_slices, pl.n_slices, oct_local, d_runs);
+            (const float*)d_slices, pl.n_slices, oct_local, d_flags, d_runs);
     lambertian_oct_final<<<dim3((oct_local + 255) / 256, 8), 256, 0, stream>>>(
-        d_runs, pl.n_runs, out_size, d_block_list, oct_begin, oct_end, oct_local, out_begin, out_count, scale,
+        d_runs, pl.n_runs, out_size, d_block_list, oct_begin, oct_end, oct_local, out_begin, out_count, scale, d_flags,
         (float4*)d_out);
     return hipGetLastError();
 }
