@@ -46,9 +46,9 @@ FLOP_PER_LAMBERTIAN_PAIR = 12       # pair by pair: dot 5, max 1, 3 FMA 6
 LAMB_FLOP_PER_LANE_RECORD = 11
 LAMB_FLOP_PER_LANE_PATTERN = 49
 # ls_pairs (the default: clamped cosine split into even and odd halves) per lane and record, as
-# issued: 1 multiply, 6 FMAs that form the four cosines (12), 8 adds of the Walsh-Hadamard
-# butterfly, 6 packed FMAs of 2 x 2 flop (24): 45.  No per-pattern part.
-LAMB_SPLIT_FLOP_PER_LANE_RECORD = 45
+# issued (hipcc -S): 2 multiplies and 2 FMAs for a+b, a-b and c (6), max, min, max, median (4),
+# 4 adds, 6 packed FMAs of 2 x 2 flop (24): 38.  No per-pattern part.
+LAMB_SPLIT_FLOP_PER_LANE_RECORD = 38
 # ggx_oct_pairs per lane, record and pattern: cosine 5, u/t/d 5, rcp + sqrt 2, two clamped ops 2,
 # three multiplies 3, the weight sum's FMA 2 (19) and 12 packed FMAs (48).
 GGX_FLOP_PER_LANE_PATTERN = 67

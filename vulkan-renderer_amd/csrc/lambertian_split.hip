@@ -17,8 +17,9 @@
 //       w^[0] = |v0| + |v4| + |v1| + |v2|      w^[3] = |v0| + |v4| - |v1| - |v2|
 //       w^[5] = |v0| - |v4| - |v1| + |v2|      w^[6] = |v0| - |v4| + |v1| - |v2|
 //   (v0 = a+b+c > 0, v4 = a+b-c, v2 = a-b+c, v1 = -a+b+c).  The records hold L^[k] for those four
-//   k (ls_prep), so one record costs 17 adds/multiplies and 12 multiply-adds per output octet
-//   instead of 11 + 49 per sign pattern that is live in the wave (lambertian_oct_pairs).
+//   k (ls_prep), so one record costs 12 vector instructions for the coefficients and 6 packed
+//   multiply-adds per output octet (ls_pairs), where lambertian_oct_pairs spends 11 and then
+//   13 more for every sign pattern that is live in the wave (4.2 on average).
 //
 // What this costs is exactness of the zero: where an output texel sees much less light than its
 // mirror images and its antipode, its value is the small difference of the two halves, and their
@@ -37,7 +38,7 @@
 //   ls_pairs     grid = (blocks of 256 output octets) x (input slices), as lambertian_oct_pairs;
 //                every wave works alone on 64 output octets and walks the slice's records with
 //                wave-uniform (scalar) loads, two register sets, the next record in flight while
-//                one is evaluated: no LDS, no barrier.  FP32 sums over 64 records, FP64 over the
+//                one is evaluated: no LDS, no barrier.  FP32 sums over 128 records, FP64 over the
 //                slice, stored as FP32 slice sums.
 //   ls_reduce / ls_final   runs of 8 slices, then all runs, in FP64; inverse transform, the odd
 //                half added, scaled, cancellation measured, stored where the range asks.
@@ -49,7 +50,9 @@ namespace ibl {
 constexpr int LS_THREADS = 256;       // 4 waves, each its own 64 output octets of the block
 constexpr int LS_REC = 4;             // float4 per input octet record
 constexpr int LS_SUMS = 12;           // 4 coefficients x RGB
-constexpr int LS_CHUNK = 64;          // records per FP32 sum
+#ifndef LS_CHUNK
+#define LS_CHUNK 128                  // records per FP32 sum (a power of two)
+#endif
 constexpr int LS_RUN = 8;             // slices per run (the same grouping as lambertian_octets.hip)
 
 __host__ __device__ inline uint32_t ls_tile_edge(uint32_t hw) {
@@ -226,22 +229,28 @@ __global__ __launch_bounds__(LS_THREADS, LS_MIN_WAVES) void ls_pairs(
     const float4* __restrict__ rp = rec + (size_t)in0 * LS_REC;      // wave-uniform
 
     auto eval = [&](const LsRec& r) __attribute__((always_inline)) {
-        const float a = n.x * __uint_as_float(r.v[0]), b = n.y * __uint_as_float(r.v[1]), cc = n.z * __uint_as_float(r.v[2]);
-        const float s1 = a + b, s2 = a - b;
-        const float v0 = s1 + cc, v4 = s1 - cc, v2 = s2 + cc, v1 = cc - s2;
-        const float p = v0 + fabsf(v4), q = v0 - fabsf(v4);
-        const float t = fabsf(v1) + fabsf(v2), u = fabsf(v2) - fabsf(v1);
-        const f32x2 w03 = f32x2{p + t, p - t};       // w^[0], w^[3]
-        const f32x2 w56 = f32x2{q + u, q - u};       // w^[5], w^[6]
-        auto pair = [&](int at) __attribute__((always_inline)) {
-            return f32x2{__uint_as_float(r.v[at]), __uint_as_float(r.v[at + 1])};
-        };
-        acc[0] = __builtin_elementwise_fma(w03.xx, pair(4), acc[0]);
-        acc[1] = __builtin_elementwise_fma(w03, pair(6), acc[1]);
-        acc[2] = __builtin_elementwise_fma(w03.yy, pair(8), acc[2]);
-        acc[3] = __builtin_elementwise_fma(w56.xx, pair(10), acc[3]);
-        acc[4] = __builtin_elementwise_fma(w56, pair(12), acc[4]);
-        acc[5] = __builtin_elementwise_fma(w56.yy, pair(14), acc[5]);
+        // |x+y| + |x-y| = 2 max(|x|, |y|) and |x+y| - |x-y| = 2 sign(xy) min(|x|, |y|) give the four
+        // coefficients, halved, from a+b, a-b and c with a max, a min, a max and a median:
+        //   (|v0| + |v4|)/2 = max(a+b, c)      (|v0| - |v4|)/2 = min(a+b, c)
+        //   (|v2| + |v1|)/2 = max(c, |a-b|)    (|v2| - |v1|)/2 = median(a-b, -c, c)
+        const float a = n.x * __uint_as_float(r.v[0]);
+        const float s1 = fmaf(n.y, __uint_as_float(r.v[1]), a), s2 = fmaf(-n.y, __uint_as_float(r.v[1]), a);
+        const float cc = n.z * __uint_as_float(r.v[2]);
+        const float p = __builtin_fmaxf(s1, cc), q = __builtin_fminf(s1, cc);
+        const float t = __builtin_fmaxf(cc, fabsf(s2)), u = __builtin_amdgcn_fmed3f(s2, -cc, cc);
+        const f32x2 w03 = f32x2{p + t, p - t};       // w^[0]/2, w^[3]/2
+        const f32x2 w56 = f32x2{q + u, q - u};       // w^[5]/2, w^[6]/2
+        // Packed multiply-adds with the record pair straight from scalar registers and the weight
+        // halves picked by operand selects (w.xx, w, w.yy): written out, because the compiler copies
+        // a weight into a second register pair for every .yy.
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        auto pair = [&](int at) __attribute__((always_inline)) { return u32x2{r.v[at], r.v[at + 1]}; };
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[0]) : "v"(w03), "s"(pair(4)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[1]) : "v"(w03), "s"(pair(6)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc[2]) : "v"(w03), "s"(pair(8)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[3]) : "v"(w56), "s"(pair(10)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[4]) : "v"(w56), "s"(pair(12)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc[5]) : "v"(w56), "s"(pair(14)));
     };
     auto flush = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -339,7 +348,8 @@ __global__ __launch_bounds__(256) void ls_final(const double* __restrict__ runs,
         double val[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const double even = e[ch] + ls_sign(3u, s) * e[3 + ch] + ls_sign(5u, s) * e[6 + ch] + ls_sign(6u, s) * e[9 + ch];
+            // (ls_pairs sums half the coefficients)
+            const double even = 2.0 * (e[ch] + ls_sign(3u, s) * e[3 + ch] + ls_sign(5u, s) * e[6 + ch] + ls_sign(6u, s) * e[9 + ch]);
             const double odd = 4.0 * (ls_sign(1u, s) * nn[0] * moment[ch] + ls_sign(2u, s) * nn[1] * moment[3 + ch] +
                                       ls_sign(4u, s) * nn[2] * moment[6 + ch]);
             const double v = even + odd;               // 8 x the sum the reference forms
