@@ -110,10 +110,10 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
 /* ibl_lambertian_dev over the whole cube for callers that cannot allocate: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart
  * in the reference.  The call allocates and frees nothing: the kernels of
- * ibl_lambertian_dev work in a 32 MiB file-scope device array of the library instead of
+ * ibl_lambertian_dev work in a 64 MiB file-scope device array of the library instead of
  * its grow-only workspaces (every GPU the library is initialised on holds that array until
  * the process ends).  Sizes whose records and partial sums do not fit the array are
- * rejected with IBL_EINVAL (512 -> 32, 256 -> 32 and 128 -> 64 texels per face edge fit),
+ * rejected with IBL_EINVAL (512 -> 32, 256 -> 64 and 128 -> 64 texels per face edge fit),
  * and so are face sizes the mirror-octet kernel does not serve (both must be even and
  * exactly mirror-symmetric, as every power of two is).  The result has the bits of
  * ibl_lambertian_dev.  All calls on one GPU share that GPU's array: calls that overlap in

@@ -31,6 +31,18 @@ def test_static_scratch_lambertian_equals_the_allocating_entry_point(ibl, orc):
         ref = orc.lambertian(env.cpu().numpy(), out_w)
         err = np.abs(got.cpu().numpy()[..., :3] - ref[..., :3]) / np.maximum(np.abs(ref[..., :3]), 1e-30)
         assert err.max() < 5e-6
+    # a light bright enough that some octets go through the second, exact-weights pass
+    env = _env(ibl, orc, 64, 5)
+    env[0, 20:24, 30:34, :3] = 1.5e3
+    got = t.full((6, 16, 16, 4), -1.0, dtype=t.float32, device=ibl.device)
+    ibl.lambertian_static(env, 16, got)
+    assert t.equal(got, ibl.lambertian(env, 16))
+    ibl.set_counting(True)
+    try:
+        ibl.lambertian(env, 16)
+        assert 0 < ibl.last_exact_octets() <= 6 * 16 * 16 // 8
+    finally:
+        ibl.set_counting(False)
 
 
 def test_static_scratch_lambertian_rejects_what_does_not_fit(ibl, orc):

@@ -122,11 +122,11 @@ void read_tuning_once() {
     if (const char* e = getenv("IBL_GGX_CORE")) g_tuning.ggx_core = (float)atof(e);
 }
 
-// The 32 MiB that ibl_lambertian_static_dev works in instead of allocated workspaces.  Every
+// The 64 MiB that ibl_lambertian_static_dev works in instead of allocated workspaces.  Every
 // device the library runs on holds its own copy of this array, at its own address, until the
 // process ends; host code reaches it only through the address hipGetSymbolAddress returns
 // with that device current (State::static_scratch).
-constexpr size_t STATIC_SCRATCH_BYTES = (size_t)32 << 20;
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)64 << 20;
 __device__ __align__(256) unsigned char g_static_scratch[STATIC_SCRATCH_BYTES];
 
 int init_device(int device) {
@@ -481,14 +481,14 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
     const uint32_t n_oct = 3 * (out_size / 2) * (out_size / 2);
     const uint32_t n_out = out_size * out_size * 6;
     ibl::LambertianOctPlan pl = ibl::lambertian_oct_plan(in_w, ibl::lambertian_oct_blocks_total(out_size));
-    // The run form stores an eighth of the partial sums and gives the same bits as the slice form.
+    // The same two passes as ibl_lambertian_dev; the exact-weights pass in its run form, which
+    // stores an eighth of the partial sums and gives the same bits as the slice form.
     pl.run = pl.n_slices > 1;
-    pl.split = false;      // exact weights in one pass: the scratch array has no room for both
     pl.partial_bytes = ibl::lambertian_oct_partial_bytes(pl);
     const size_t rec_bytes = (pl.rec_bytes + 255) & ~(size_t)255;
     if (rec_bytes + pl.partial_bytes > STATIC_SCRATCH_BYTES)
         return fail(IBL_EINVAL, "lambertian_static: %u x %u/face -> %u x %u/face needs %zu bytes of scratch, the "
-                    "static array holds %zu (e.g. 512 -> 32, 256 -> 32, 128 -> 64 fit); use ibl_lambertian_dev",
+                    "static array holds %zu (e.g. 512 -> 32, 256 -> 64, 128 -> 64 fit); use ibl_lambertian_dev",
                     in_w, in_w, out_size, out_size, rec_bytes + pl.partial_bytes, STATIC_SCRATCH_BYTES);
     S->last_counts[0] = 0;
     S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
