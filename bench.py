@@ -460,7 +460,10 @@ def main():
             line["roofline"]["exact_weight_octets"] = wl.exact_octets
         try:   # measured HBM traffic of the same launch, from the committed rocprofv3 PMC passes
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tr = json.load(f).get(wl.name)
+                table = json.load(f)
+            tr = table.get(wl.name)
+            if tr and not tr["kernel"].startswith(wl.kernel):       # the same workload on another kernel
+                tr = next((v for k, v in table.items() if k.startswith(wl.name + "_") and v["kernel"].startswith(wl.kernel)), None)
             if tr and world == 1 and not getattr(wl, "ggx_samples", 0):
                 line["roofline"]["traffic"] = tr["bytes"]
                 line["roofline"]["traffic_source"] = tr["source"]
