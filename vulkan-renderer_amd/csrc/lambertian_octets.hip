@@ -433,12 +433,14 @@ LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks) {
     pl.n_oct_in = 3 * (in_w / 2) * (in_w / 2);
     // Slice length depends on the input size only (range/shard independence).
     uint32_t tiles = (pl.n_oct_in + OCT_TILE - 1) / OCT_TILE;
-    // At most 304 slices (300 for a 1024 x 1024 face).  More slices fill a GPU better when a call
-    // covers few output blocks (an eighth of 1024 -> 128, one of 8 GPUs: 2.52 ms with 512 slices,
-    // 2.58 with 384, 2.69 with 256; the whole cube on one GPU: 19.4 ms with any of them), fewer
-    // slices write fewer partial sums (1.18 MB each for that cube): 300 keep the kernel's memory
-    // traffic below three times the bytes it has to move anyway.
-    uint32_t max_slices = tuning().lamb_oct_slices ? tuning().lamb_oct_slices : 304;
+    // At most 341 slices (333 for a 1024 x 1024 face).  The count fixes the order of the sums, so it
+    // may depend on the input size only; it is chosen for the 1024 -> 128 cube on 1, 2, 4 and 8 GPUs
+    // at once: 48 / N output blocks x 333 slices is 7.8, 3.9, 1.95 and 0.98 times the 2048 workgroups
+    // a GPU holds (8 per CU), so a shard never leaves a CU with one workgroup more than its
+    // neighbours for a whole slice (an eighth of the cube: 0.61 ms with 333 slices, 0.67 with 300,
+    // 0.96 with 384; the whole cube on one GPU 4.5-4.6 ms with any of them), and the slice sums stay
+    // below twice the bytes the kernel has to move anyway.
+    uint32_t max_slices = tuning().lamb_oct_slices ? tuning().lamb_oct_slices : 341;
     uint32_t tiles_per_slice = (tiles + max_slices - 1) / max_slices;
     if (tiles_per_slice < 2) tiles_per_slice = 2;
     pl.slice_len = tiles_per_slice * OCT_TILE;
