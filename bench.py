@@ -93,6 +93,7 @@ class Workload:
         self.sharding, self.capi = sharding, capi
         t = ibl.torch
         self.kernel_ms = []
+        self.pending_kernel_ms = 0
         self.executed_flop_per_launch = None
         if name in ("c1", "c4"):
             self.in_w, self.out_w = (64, 32) if name == "c1" else (1024, 128)
@@ -207,6 +208,12 @@ class Workload:
             self.bytes_per_launch = 8 * self.count
         self.np = np
 
+    def collect_kernel_ms(self):
+        """Kernel durations of the steps whose event pairs have not been read yet."""
+        for back in range(self.pending_kernel_ms - 1, -1, -1):
+            self.kernel_ms.append(self.ibl.kernel_ms_back(back))
+        self.pending_kernel_ms = 0
+
     def _gather(self, kind, in_w, cube, mip=1, mips=1):
         """The exchange step: pack this rank's shard, one all-gather, scatter every shard."""
         self.sharding.gather_cube(self.dist, self.ibl, kind, in_w, cube, mip, mips, self.rank, self.world,
@@ -216,7 +223,11 @@ class Workload:
         ibl, d = self.ibl, self.dist
         if self.name in ("c1", "c4"):
             ibl.lambertian_shard(self.env, self.out_w, self.rank, self.world, out=self.out)
-            self.kernel_ms.append(ibl.last_kernel_ms() if self.count else 0.0)
+            # (kernel times are read after the loop, from the library's ring of event pairs: a wait
+            # here would expose the host's launch latency once per 4 ms step)
+            self.pending_kernel_ms += 1 if self.count else 0
+            if self.pending_kernel_ms == 60:
+                self.collect_kernel_ms()
             self._gather(self.capi.SHARD_LAMBERTIAN, self.in_w, self.out)
         elif self.name in ("c3", "c5"):
             if self.name == "c5":
@@ -337,13 +348,15 @@ def run_timed(wl, steps, warmup, torch, dist, world, device):
 
     for _ in range(warmup):
         wl.step()
-    wl.kernel_ms.clear()
     fence()
+    wl.collect_kernel_ms()
+    wl.kernel_ms.clear()
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step()
     fence()
     elapsed = time.perf_counter() - t0
+    wl.collect_kernel_ms()
     kernel_ms = sum(wl.kernel_ms) / max(len(wl.kernel_ms), 1)
     if world > 1:
         tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if wl.via_host else device)

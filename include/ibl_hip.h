@@ -307,6 +307,11 @@ int ibl_get_tuning(const char* name, double* value);
 int ibl_set_timing(int enabled);
 /* Waits for the last bracketed kernel and returns its duration in ms. */
 int ibl_last_kernel_ms(float* ms);
+/* The same for an earlier timed call on this device: calls_back 0 is the last one, 1 the one
+ * before, ... (the library keeps the event pairs of the last 64 timed calls; a call that had
+ * nothing to launch records none and does not count).  Lets a caller queue a series of calls
+ * and read their kernel times afterwards, without a wait between them. */
+int ibl_kernel_ms_back(uint32_t calls_back, float* ms);
 /* Work done by the last lambertian/ggx *_dev call as the kernels counted it
  * (GGX counts need ibl_set_counting(1); they cost a few percent). */
 int ibl_set_counting(int enabled);

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "ibl_last_kernel_ms": ([ctypes.POINTER(ctypes.c_float)], _int),
     "ibl_set_counting": ([_int], _int),
     "ibl_last_counts": ([ctypes.POINTER(_u64)] * 3, _int),
+    "ibl_kernel_ms_back": ([_u32, ctypes.POINTER(ctypes.c_float)], _int),
     "ibl_last_wave_work": ([ctypes.POINTER(_u64)] * 2, _int),
 }
 
@@ -375,6 +376,11 @@ class Ibl:
     def last_kernel_ms(self):
         ms = ctypes.c_float()
         self._check(self.lib.ibl_last_kernel_ms(ctypes.byref(ms)))
+        return ms.value
+
+    def kernel_ms_back(self, calls_back):
+        ms = ctypes.c_float()
+        self._check(self.lib.ibl_kernel_ms_back(int(calls_back), ctypes.byref(ms)))
         return ms.value
 
     def set_counting(self, on):

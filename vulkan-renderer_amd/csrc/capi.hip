@@ -41,11 +41,18 @@ struct Buffer {
     size_t cap = 0;
 };
 
+constexpr int TIMING_RING = 64;
+
 struct State {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;   // host-buffer entry points run on the default stream
+    // Timing: a ring of event pairs, one per timed call, so that a caller can queue many calls
+    // and read their kernel times afterwards without waiting in between.  ev0 / ev1 are the pair
+    // the next timed call records; timed_calls counts the calls that have recorded one.
+    hipEvent_t ring0[TIMING_RING] = {}, ring1[TIMING_RING] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t timed_calls = 0;
     bool timing = false, counting = false, timed_valid = false;
     Buffer a, b, pn, partial, counts, stage_in, stage_out, units;
     void* static_scratch = nullptr; // this device's copy of the file-scope scratch array (ibl_lambertian_static_dev)
@@ -139,12 +146,21 @@ int init_device(int device) {
         return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
     void* scratch = nullptr;
     HIP_TRY(hipGetSymbolAddress(&scratch, HIP_SYMBOL(g_static_scratch)));
-    HIP_TRY(hipEventCreate(&st.ev0));
-    if (hipError_t e1 = hipEventCreate(&st.ev1); e1 != hipSuccess) {
-        (void)hipEventDestroy(st.ev0);
-        st.ev0 = nullptr;
-        return fail(IBL_EHIP, "hipEventCreate: %s", hipGetErrorString(e1));
+    for (int k = 0; k < TIMING_RING; k++) {
+        hipError_t e0 = hipEventCreate(&st.ring0[k]);
+        hipError_t e1 = e0 == hipSuccess ? hipEventCreate(&st.ring1[k]) : e0;
+        if (e1 != hipSuccess) {
+            for (int j = 0; j <= k; j++) {
+                if (st.ring0[j]) (void)hipEventDestroy(st.ring0[j]);
+                if (st.ring1[j]) (void)hipEventDestroy(st.ring1[j]);
+                st.ring0[j] = st.ring1[j] = nullptr;
+            }
+            return fail(IBL_EHIP, "hipEventCreate: %s", hipGetErrorString(e1));
+        }
     }
+    st.ev0 = st.ring0[0];
+    st.ev1 = st.ring1[0];
+    st.timed_calls = 0;
     st.static_scratch = scratch;
     st.device = device;
     st.ready = true;
@@ -158,8 +174,10 @@ void shutdown_device(int device) {
     (void)hipDeviceSynchronize();
     release(st.a); release(st.b); release(st.pn); release(st.partial); release(st.counts);
     release(st.stage_in); release(st.stage_out); release(st.units);
-    if (st.ev0) (void)hipEventDestroy(st.ev0);
-    if (st.ev1) (void)hipEventDestroy(st.ev1);
+    for (int k = 0; k < TIMING_RING; k++) {
+        if (st.ring0[k]) (void)hipEventDestroy(st.ring0[k]);
+        if (st.ring1[k]) (void)hipEventDestroy(st.ring1[k]);
+    }
     st = State();
 }
 
@@ -194,6 +212,15 @@ int check_cube(uint32_t w, uint32_t h, const char* what) {
     if (w != h) return fail(IBL_EINVAL, "%s: cube faces must be square, got %ux%u", what, w, h);
     if ((uint64_t)w * h * 6 > 0x7fffffffull / 4) return fail(IBL_EINVAL, "%s: cube %ux%u too large", what, w, h);
     return IBL_OK;
+}
+
+// A *_dev call that has recorded its event pair: the next timed call gets the next pair.
+void finish_timed_call() {
+    S->timed_valid = S->timing;
+    if (!S->timing) return;
+    S->timed_calls++;
+    S->ev0 = S->ring0[S->timed_calls % TIMING_RING];
+    S->ev1 = S->ring1[S->timed_calls % TIMING_RING];
 }
 
 int check_range(uint32_t begin, uint32_t count, uint64_t total, const char* what) {
@@ -346,8 +373,21 @@ int ibl_last_kernel_ms(float* ms) {
     if (int rc = check_ready()) return rc;
     if (!ms) return fail(IBL_EINVAL, "ms is null");
     if (!S->timed_valid) return fail(IBL_EINVAL, "no timed kernel: call ibl_set_timing(1) before a *_dev call");
-    HIP_TRY(hipEventSynchronize(S->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, S->ev0, S->ev1));
+    const uint64_t slot = (S->timed_calls - 1) % TIMING_RING;
+    HIP_TRY(hipEventSynchronize(S->ring1[slot]));
+    HIP_TRY(hipEventElapsedTime(ms, S->ring0[slot], S->ring1[slot]));
+    return IBL_OK;
+}
+
+int ibl_kernel_ms_back(uint32_t calls_back, float* ms) {
+    if (int rc = check_ready()) return rc;
+    if (!ms) return fail(IBL_EINVAL, "ms is null");
+    if (calls_back >= (uint32_t)TIMING_RING || calls_back >= S->timed_calls)
+        return fail(IBL_EINVAL, "kernel_ms_back: %u calls back, but %llu timed calls so far and %d are kept",
+                    calls_back, (unsigned long long)S->timed_calls, TIMING_RING);
+    const uint64_t slot = (S->timed_calls - 1 - calls_back) % TIMING_RING;
+    HIP_TRY(hipEventSynchronize(S->ring1[slot]));
+    HIP_TRY(hipEventElapsedTime(ms, S->ring0[slot], S->ring1[slot]));
     return IBL_OK;
 }
 
@@ -427,7 +467,7 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
                                        (double*)S->partial.ptr, s, S->timing ? S->ev0 : nullptr,
                                        S->timing ? S->ev1 : nullptr));
     }
-    S->timed_valid = S->timing;
+    finish_timed_call();
     return IBL_OK;
 }
 
@@ -465,7 +505,7 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
                                        S->a.ptr, (double*)S->partial.ptr, d_counts, pick(stream),
                                        S->timing ? S->ev0 : nullptr, S->timing ? S->ev1 : nullptr));
     S->counts_pending = S->counting ? 2 : 0;
-    S->timed_valid = S->timing;
+    finish_timed_call();
     return IBL_OK;
 }
 
@@ -499,7 +539,7 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
     HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, nullptr, 0, n_oct, 0, n_out, d_out, base,
                                        (double*)(base + rec_bytes), nullptr, pick(stream), S->timing ? S->ev0 : nullptr,
                                        S->timing ? S->ev1 : nullptr));
-    S->timed_valid = S->timing;
+    finish_timed_call();
     return IBL_OK;
 }
 
@@ -541,7 +581,7 @@ int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t m
     HIP_TRY(ibl::ggx_oct_launch(pl, d_env, in_w, out_w, (const uint32_t*)S->units.ptr, out_begin, out_count, d_out,
                                 S->a.ptr, S->pn.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
                                 S->timing ? S->ev1 : nullptr));
-    S->timed_valid = S->timing;
+    finish_timed_call();
     S->counts_pending = S->counting ? 1 : 0;
     return IBL_OK;
 }
@@ -589,7 +629,7 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
     HIP_TRY(ibl::ggx_launch(pl, d_env, in_w, in_h, out_w, out_h, out_begin, out_count, d_out, S->a.ptr, S->b.ptr,
                             S->pn.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
                             S->timing ? S->ev1 : nullptr));
-    S->timed_valid = S->timing;
+    finish_timed_call();
     S->counts_pending = S->counting ? 1 : 0;
     return IBL_OK;
 }
@@ -766,7 +806,7 @@ int ibl_brdf_lut_dev(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, ui
     hipStream_t s = pick(stream);
     HIP_TRY(ibl::brdf_lut_launch(n_rough, n_cos, samples_sqrt, seed, jitter_mode, cell_begin, cell_count, d_out, s,
                                  S->timing ? S->ev0 : nullptr, S->timing ? S->ev1 : nullptr));
-    S->timed_valid = S->timing;
+    finish_timed_call();
     return IBL_OK;
 }
 
@@ -841,7 +881,7 @@ int ibl_ggx_level_sampled_dev(const float* d_pyramid, uint32_t in_w, uint32_t ou
     HIP_TRY(ibl::ggx_sampled_launch(d_pyramid, in_w, out_w, mip_level, mip_levels, n_samples, lod_bias, out_begin,
                                     out_count, d_out, pick(stream), S->timing ? S->ev0 : nullptr,
                                     S->timing ? S->ev1 : nullptr));
-    S->timed_valid = S->timing;
+    finish_timed_call();
     return IBL_OK;
 }
 
