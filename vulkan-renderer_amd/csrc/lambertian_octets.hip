@@ -1,4 +1,7 @@
-// Lambertian irradiance through the cube's mirror symmetry (gfx950).
+// Lambertian irradiance through the cube's mirror symmetry, with the reference's own per-pair
+// weights (gfx950).  lambertian_split.hip evaluates the same sum with a quarter of the
+// arithmetic and is what runs first; the kernels of this file then redo the output octets whose
+// texels that form cannot hold to ~1e-6 (or everything, with the knob "lamb_split" at 0).
 //
 // Same sum as lambertian.hip (integrateLambertian, src/utilities/cube.cpp:95-129),
 // evaluated octet against octet.  With canonical (all-positive) components of an
@@ -10,8 +13,9 @@
 // and what remains is the 56 x 3 colour FMAs: 180 VALU instructions per 64 texel
 // pairs instead of 384.  Of the six remaining non-trivial patterns, opposite ones
 // cancel: per lane exactly three are positive, and a wave of neighbouring octets
-// mostly agrees on which, so usually 32 x 3 FMAs are issued, not 56 x 3.  The reference computes each of those 64 products with the
-// same operands in the same order, so sharing them changes nothing it could see.
+// mostly agrees on which, so usually 32 x 3 FMAs are issued, not 56 x 3.  The reference
+// computes each of those 64 products with the same operands in the same order, so sharing
+// them changes nothing it could see.
 //
 // Kernel plan
 //   lambertian_oct_prep    one thread per input octet: canonical g and the 8
@@ -19,9 +23,10 @@
 //                          as 7 float4 (112 B): a packed FMA then reads two neighbouring
 //                          members of one channel, swapped by op_sel where the pattern
 //                          flips x.
-//   lambertian_oct_pairs   grid = (blocks of 256 output octets) x (input slices);
-//                          a thread owns one output octet: 24 FP32 sums over one
-//                          LDS tile of 64 input octets, then FP64 running sums.
+//   lambertian_oct_pairs   grid = (blocks of 256 output octets) x (input slices, dealt to the
+//                          XCDs); a thread owns one output octet: 24 FP32 sums over one
+//                          LDS tile of 64 input octets, FP64 sums over the slice, stored as
+//                          FP32 slice sums (or, in the run form, FP64 sums of 8 slices).
 //   lambertian_oct_reduce / lambertian_oct_final
 //                          per output octet: slices summed in a fixed two-stage order in FP64,
 //                          scaled, scattered to the 8 member texels that lie in the
