@@ -49,9 +49,12 @@ LAMB_FLOP_PER_LANE_PATTERN = 49
 # issued (hipcc -S): 2 multiplies and 2 FMAs for a+b, a-b and c (6), max, min, max, median (4),
 # 4 adds, 6 packed FMAs of 2 x 2 flop (24): 38.  No per-pattern part.
 LAMB_SPLIT_FLOP_PER_LANE_RECORD = 38
-# ggx_oct_pairs per lane, record and pattern: cosine 5, u/t/d 5, rcp + sqrt 2, two clamped ops 2,
-# three multiplies 3, the weight sum's FMA 2 (19) and 12 packed FMAs (48).
-GGX_FLOP_PER_LANE_PATTERN = 67
+# ggx_oct_pairs per lane, record and pattern: cosine 5 (every record walked); then, for the records
+# evaluated (all of them at narrow lobes; at wide lobes those some lane of the wave accepts):
+# u/t/d 5, rcp + sqrt 2, two clamped ops 2, three multiplies 3, the weight sum's FMA 2 and 12 packed
+# FMAs (48): 62.
+GGX_FLOP_PER_LANE_WALKED = 5
+GGX_FLOP_PER_LANE_EVALUATED = 62
 FLOP_PER_GGX_ACCEPTED = 30          # pair by pair
 FLOP_PER_GGX_REJECTED = 8
 FLOP_PER_LUT_SAMPLE = 40
@@ -150,6 +153,7 @@ class Workload:
                 ibl.ggx_level_shard(self.env, lv["ow"], lv["m"], self.mips, rank, world, out=lv["out"])
                 c = ibl.last_counts()
                 lv["my_tested"], lv["my_accepted"], lv["my_wave_records"] = c["tested"], c["accepted"], c["wave_records"]
+                lv["my_wave_evaluated"] = c["wave_patterns"]
                 mine += [c["tested"], c["accepted"]]
             ibl.set_counting(False)
             tot = t.tensor(mine, dtype=t.float64, device="cpu" if self.via_host else ibl.device)
@@ -166,7 +170,8 @@ class Workload:
             self.flop_per_launch = (FLOP_PER_GGX_ACCEPTED * lv1["my_accepted"]
                                     + FLOP_PER_GGX_REJECTED * (lv1["my_tested"] - lv1["my_accepted"]))
             if lv1["my_wave_records"]:
-                self.executed_flop_per_launch = 64.0 * GGX_FLOP_PER_LANE_PATTERN * lv1["my_wave_records"]
+                self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED * lv1["my_wave_records"]
+                                                        + GGX_FLOP_PER_LANE_EVALUATED * lv1["my_wave_evaluated"])
             self.kernel = "ggx_oct_pairs (level 1)"
             self.desc = ("C%s: GGX prefilter chain of a %dx%d/face environment, %d levels, --input-downscale %d; "
                          "samples = in-patch texel tests (%.3g tested, %.3g accepted)"

@@ -308,6 +308,7 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "ggx_waves")) g_tuning.ggx_waves = value;
     else if (!strcmp(name, "ggx_xcd_slices")) g_tuning.ggx_xcd_slices = (int)value;
     else if (!strcmp(name, "ggx_core")) g_tuning.ggx_core = (float)value;
+    else if (!strcmp(name, "ggx_early")) g_tuning.ggx_early = (int)value;
     else if (!strcmp(name, "bake_rehearse_shards")) g_tuning.bake_rehearse_shards = (int)value;
     else return fail(IBL_EINVAL, "set_tuning: unknown knob %s", name);
     return IBL_OK;
@@ -325,6 +326,7 @@ int ibl_get_tuning(const char* name, double* value) {
     else if (!strcmp(name, "ggx_waves")) *value = g_tuning.ggx_waves;
     else if (!strcmp(name, "ggx_xcd_slices")) *value = g_tuning.ggx_xcd_slices;
     else if (!strcmp(name, "ggx_core")) *value = g_tuning.ggx_core;
+    else if (!strcmp(name, "ggx_early")) *value = g_tuning.ggx_early;
     else if (!strcmp(name, "bake_rehearse_shards")) *value = g_tuning.bake_rehearse_shards;
     else if (!strcmp(name, "general_only")) *value = g_tuning.no_octets ? 1.0 : 0.0;
     else return fail(IBL_EINVAL, "get_tuning: unknown knob %s", name);

@@ -201,7 +201,12 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
 #ifndef GO_MIN_WAVES
 #define GO_MIN_WAVES 6
 #endif
-template <bool COUNT>
+// EARLY (wide lobes: the acceptance window reaches the horizon): a record that no lane of the
+// wave accepts is dropped after its cosine.  The reference's patch test keeps whole 16 x 16 patches
+// that straddle the window's edge, and at these levels a third of the texels it then tests fail
+// (cube.cpp:271); a wave's 64 directions lie within a few degrees, so they mostly fail together.
+// Narrow lobes accept 99 % of what the patch test lets through and skip the test.
+template <bool COUNT, bool EARLY>
 __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn, const uint32_t* __restrict__ units,
     uint32_t n_po, uint32_t ps2,
@@ -219,20 +224,23 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
     // xcd_runs the grid is laid out so that XCD k only ever works on runs k, k + 8, ...:
     // the records an XCD's L2 has to hold are then those of one run's current subset, however
     // many runs are in flight on the chip.  The host asks for it where that matters (narrow
-    // lobes, few units).  (One argument carries the run count and, in its top bit, the order:
+    // lobes, few units).
+    // (One argument carries the level's run count, the first run of this launch and the order:
     // scalar registers are short in this kernel.)
-    const uint32_t n_runs = runs_and_order & 0x7fffffffu;
+    const uint32_t n_runs = runs_and_order & 0x7fffu;                // runs of the level
+    const uint32_t run_base = (runs_and_order >> 15) & 0x7fffu;      // first run of this launch
     const bool xcd_runs = (runs_and_order >> 31) != 0u;
     const uint32_t n_units = oct_local / GO_UNIT;
-    uint32_t run, wv;                                                // wv: this wave's unit among the call's
-    if (xcd_runs) {                                                  // n_runs is a multiple of 8 then
+    uint32_t run_local, wv;                                          // wv: this wave's unit among the call's
+    if (xcd_runs) {                                                  // the launch's run count is a multiple of 8 then
         const uint32_t seq = blockIdx.x / 8;
-        run = blockIdx.x % 8 + 8 * (seq / n_units);
+        run_local = blockIdx.x % 8 + 8 * (seq / n_units);
         wv = seq % n_units;
     } else {
-        run = blockIdx.x / n_units;
+        run_local = blockIdx.x / n_units;
         wv = blockIdx.x % n_units;
     }
+    const uint32_t run = run_base + run_local;
     const uint32_t lo = wv * GO_UNIT + lane;
     const uint32_t gidx = go_global(lo, units);
     const bool lane_valid = gidx < n_oct;
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
 #pragma unroll
     for (int k = 0; k < GO_SUMS; k++) s_run[k][lane] = 0.0f;
     uint32_t n_accepted = 0;
-    unsigned long long tot_tested = 0, tot_accepted = 0, tot_walked = 0;
+    unsigned long long tot_tested = 0, tot_accepted = 0, tot_walked = 0, tot_evaluated = 0;
 
     // Three levels of sums, all in a fixed order: FP32 chunks of at most 256 terms in registers;
     // the run's FP32 running sums of its chunks (a few dozen) in LDS, indexed by output member;
@@ -405,6 +413,9 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
                     acc_terms += ps2;
                     // this lane's cutoff for the walk (2 if its patch test failed: weight 0)
                     const float thr = ((lane_pass >> tau) & 1u) ? (COUNT ? cmin : cutoff) : 2.0f;
+                    // (EARLY) the lanes whose patch test passed, as a scalar mask: a register per lane
+                    // for it would be the one too many
+                    const unsigned long long pass_mask = EARLY ? __ballot(((lane_pass >> tau) & 1u) != 0u) : 0ull;
                     const F3 nt = { __uint_as_float(__float_as_uint(n.x) ^ ((tau & 1u) << 31)),
                                     __uint_as_float(__float_as_uint(n.y) ^ ((tau & 2u) << 30)),
                                     __uint_as_float(__float_as_uint(n.z) ^ ((tau & 4u) << 29)) };
@@ -423,6 +434,8 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
                             float c = nt.x * r[0];
                             c = fmaf(nt.y, r[1], c);
                             c = fmaf(nt.z, r[2], c);
+                            if (EARLY && (__ballot(c > cmin) & pass_mask) == 0ull) return;      // weight 0 in every lane
+                            if (COUNT) tot_evaluated += 1;
                             go_body<COUNT, CORE>(c, r, thr, a2p, kc, nt, acc, accw, n_accepted);
                         };
                         go_rec_load(ra, rp);
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
     if (lane_valid) {
 #pragma unroll
         for (int k = 0; k < GO_SUMS; k++)
-            partial[((size_t)run * GO_SUMS + k) * oct_local + lo] = s_run[k][lane];
+            partial[((size_t)run_local * GO_SUMS + k) * oct_local + lo] = s_run[k][lane];
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -458,8 +471,8 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
         if (lane == 0) {
             atomicAdd(&counts[1], tot_tested);
             atomicAdd(&counts[2], tot_accepted);
-            atomicAdd(&counts[3], tot_walked);       // records this wave evaluated (64 lanes each),
-            atomicAdd(&counts[4], tot_walked);       // one sign pattern per record and walk
+            atomicAdd(&counts[3], tot_walked);       // records this wave walked (64 lanes each, once per live pattern),
+            atomicAdd(&counts[4], tot_evaluated);    // ... and those it evaluated past the cosine
         }
     }
 }
@@ -467,8 +480,9 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
 // First stage of the run sum when a level has many runs: group g adds its stretch of
 // consecutive runs, in order, into one more set of partial sums.  One thread per
 // (output octet, member, group).
+// (partial holds the n_runs runs of one launch; its groups are group_base, group_base + 1, ...)
 __global__ __launch_bounds__(256) void ggx_oct_reduce(const float* __restrict__ partial, uint32_t n_runs,
-                                                       uint32_t per_group, uint32_t n_oct,
+                                                       uint32_t per_group, uint32_t group_base, uint32_t n_oct,
                                                        const uint32_t* __restrict__ units, uint32_t oct_count,
                                                        double* __restrict__ reduced) {
     const uint32_t lo = blockIdx.x * GO_THREADS + threadIdx.x;
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(256) void ggx_oct_reduce(const float* __restrict__ 
     for (uint32_t sl = s0; sl < s1; sl++) {
         for (uint32_t k = 0; k < nj; k++) v[k] += (double)partial[((size_t)sl * GO_SUMS + (j0 + k)) * oct_count + lo];
     }
-    for (uint32_t k = 0; k < nj; k++) reduced[((size_t)g * GO_SUMS + (j0 + k)) * oct_count + lo] = v[k];
+    for (uint32_t k = 0; k < nj; k++) reduced[((size_t)(group_base + g) * GO_SUMS + (j0 + k)) * oct_count + lo] = v[k];
 }
 
 // One thread per (output octet, member): coalesced over the octet index.  T: float (the runs'
@@ -548,8 +562,8 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     // output units; together they read a good part of that run's records, each many times, and
     // that set should sit in the XCD's 4 MiB L2.  Measured on the 2048 -> 1024 level with the
     // runs dealt to the XCDs: 2 and 3.7 MiB of records per run 755 ms, 7.3 MiB 849 ms, 14.7 MiB
-    // 1004 ms.  So at most 4 MiB of records per run -- as long as the partial sums that costs
-    // stay below 4 GiB (2048 -> 1024: 48 runs, 3.8 GB; twice the runs would be 11 % faster).
+    // 1004 ms.  So at most 4 MiB of records per run; the partial sums that costs are kept below
+    // 4 GiB by launching the runs in several passes (below).
     {
         const double rec_total = (double)pl.n_po * ps * ps * GO_REC * sizeof(float4);
         const double per_run = (double)units_level * GO_UNIT * GO_SUMS * sizeof(float);
@@ -562,22 +576,39 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
         if (tuning().ggx_waves <= 0.0) {
             if ((double)want > modest) want = modest >= 1.0 ? (uint32_t)modest : 1u;
             if (fit > (double)want) want = (uint32_t)fit;
-            if ((double)want > afford) want = afford >= 1.0 ? (uint32_t)afford : 1u;
         }
+        uint32_t max_runs = pl.n_po < 32767u ? pl.n_po : 32767u;     // at least one patch octet per run
+        if (max_runs == 0) max_runs = 1;
+        uint32_t runs = want < 1 ? 1 : (want > max_runs ? max_runs : want);
+        // What 4 GiB cannot hold at once is done in several launches over the same buffer, each
+        // followed by its groups' sums (2048 -> 1024: 96 runs as 2 x 48; the same bits as one launch).
+        uint32_t passes = (uint32_t)ceil((double)runs / (afford >= 1.0 ? afford : 1.0));
+        if (passes < 1) passes = 1;
+        // a multiple of 8 per launch, so that the 8 XCDs can own equal shares of the runs (see ggx_oct_pairs)
+        uint32_t per_pass = (runs + passes - 1) / passes;
+        if (passes > 1) per_pass = (per_pass + 7) / 8 * 8;
+        else if (per_pass >= 16) per_pass = per_pass / 8 * 8;
+        while (passes > 1 && (double)per_pass > afford) { passes++; per_pass = ((runs + passes - 1) / passes + 7) / 8 * 8; }
+        pl.passes = passes;
+        pl.runs_per_pass = per_pass;
+        pl.n_runs = per_pass * passes;
     }
-    uint32_t max_runs = pl.n_po;                             // at least one patch octet per run
-    if (max_runs == 0) max_runs = 1;
-    uint32_t runs = want < 1 ? 1 : (want > max_runs ? max_runs : want);
-    // a multiple of 8, so that the 8 XCDs can own equal shares of the runs (see ggx_oct_pairs)
-    if (runs >= 16) runs = runs / 8 * 8;
-    pl.n_runs = runs;
     pl.out_units = n_units;
     const uint32_t oct_count = pl.out_units * GO_UNIT;
-    // many runs are summed in two stages (fixed grouping, so still one summation order)
-    pl.reduce_groups = pl.n_runs > 64 ? (pl.n_runs + 31) / 32 : 1;
-    if (pl.reduce_groups > 64) pl.reduce_groups = 64;
+    // many runs are summed in two stages (fixed grouping, so still one summation order); a group
+    // never spans two launches
+    if (pl.passes > 1) {
+        pl.per_group = pl.runs_per_pass;
+        for (uint32_t g = 32; g >= 8; g--)
+            if (pl.runs_per_pass % g == 0) { pl.per_group = g; break; }
+        pl.reduce_groups = pl.n_runs / pl.per_group;
+    } else {
+        pl.reduce_groups = pl.n_runs > 64 ? (pl.n_runs + 31) / 32 : 1;
+        if (pl.reduce_groups > 64) pl.reduce_groups = 64;
+        pl.per_group = (pl.n_runs + pl.reduce_groups - 1) / pl.reduce_groups;
+    }
     const uint32_t stage2 = pl.reduce_groups > 1 ? pl.reduce_groups : 0;
-    pl.partial_bytes = (size_t)GO_SUMS * oct_count * (pl.n_runs * sizeof(float) + stage2 * sizeof(double));
+    pl.partial_bytes = (size_t)GO_SUMS * oct_count * (pl.runs_per_pass * sizeof(float) + stage2 * sizeof(double));
     pl.rec_bytes = (size_t)pl.n_po * ps * ps * GO_REC * sizeof(float4);
     pl.pn_bytes = (size_t)pl.n_po * sizeof(float4);
     return pl;
@@ -603,35 +634,51 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     // at 96 runs: 1685 -> 1406 ms; wide-lobe levels with small runs lose 1-3 % with it).
     const double cone = 0.5 * (1.0 - fmax(0.0, 2.0 * (double)pl.lv.cutoff - 1.0));
     const double run_bytes = (double)pl.rec_bytes / (double)pl.n_runs;
-    uint32_t xcd_runs = (pl.n_runs % 8 == 0 && (8.0 * cone < 1.5 || run_bytes > (double)(2u << 20))) ? 1u : 0u;
-    if (tuning().ggx_xcd_slices >= 0) xcd_runs = (tuning().ggx_xcd_slices != 0 && pl.n_runs % 8 == 0) ? 1u : 0u;
-    const dim3 grid(pl.n_runs * pl.out_units);
+    uint32_t xcd_runs = (pl.runs_per_pass % 8 == 0 && (8.0 * cone < 1.5 || run_bytes > (double)(2u << 20))) ? 1u : 0u;
+    if (tuning().ggx_xcd_slices >= 0) xcd_runs = (tuning().ggx_xcd_slices != 0 && pl.runs_per_pass % 8 == 0) ? 1u : 0u;
+    const dim3 grid(pl.runs_per_pass * pl.out_units);
     const uint32_t small_blocks = (pl.out_units * GO_UNIT + GO_THREADS - 1) / GO_THREADS;
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
     const uint32_t oct_count = pl.out_units * GO_UNIT;
-    // workspace: the groups' sums (double) first, then the runs' sums (float)
+    // workspace: the groups' sums (double) first, then the sums of one launch's runs (float)
     double* d_groups = d_partial;
     float* d_runs = (float*)(d_partial + (size_t)(pl.reduce_groups > 1 ? pl.reduce_groups : 0) * GO_SUMS * oct_count);
+    const bool early = cmin == 0.0f && tuning().ggx_early != 0;      // the window reaches the horizon
+    // At those levels the reference's patch test lets patches through up to acos(2 cutoff - 1) > 90
+    // degrees from an output direction, and then rejects every one of their texels below the
+    // horizon (cube.cpp:271): a third to a half of the texels it tests.  A patch octet further than
+    // 90 degrees + its own angular radius from every direction of a wave has weight 0 throughout,
+    // so the wave's bounding-cone test leaves it out (the counting variant keeps the reference's
+    // angle: its counts are the reference's).
+    const float theta_walk = early ? fminf(theta_acc, 1.5707964f + 1.4143f / (float)pw) : theta_acc;
+    // The per-record test (EARLY) makes every record wait for a vector compare to reach a scalar
+    // branch: worth it only while other waves fill that time (512 -> 16: 2304 waves, 0.37 -> 0.54 ms
+    // with it).  It changes no sum -- a skipped record has weight 0 in every lane -- so the choice
+    // may depend on the call's size.
+    const bool early_records = early && (uint64_t)pl.runs_per_pass * pl.out_units >= 24576u;
     if (ev0) (void)hipEventRecord(ev0, stream);
-    if (d_counts)
-        ggx_oct_pairs<true><<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, d_units, pl.n_po,
-            ps2, out_w, pl.tw, n_oct, oct_count, pl.n_runs | (xcd_runs << 31), out_begin, out_count,
-            pl.lv.cutoff, a2m1, cmin, theta_acc, core_thr, d_runs, d_counts);
-    else
-        ggx_oct_pairs<false><<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, d_units, pl.n_po,
-            ps2, out_w, pl.tw, n_oct, oct_count, pl.n_runs | (xcd_runs << 31), out_begin, out_count,
-            pl.lv.cutoff, a2m1, cmin, theta_acc, core_thr, d_runs, d_counts);
-    if (ev1) (void)hipEventRecord(ev1, stream);
-    if (pl.reduce_groups > 1) {
-        const uint32_t per_group = (pl.n_runs + pl.reduce_groups - 1) / pl.reduce_groups;
-        ggx_oct_reduce<<<dim3(small_blocks, 9, pl.reduce_groups), GO_THREADS, 0, stream>>>(
-            d_runs, pl.n_runs, per_group, n_oct, d_units, oct_count, d_groups);
+    for (uint32_t pass = 0; pass < pl.passes; pass++) {
+        const uint32_t run_base = pass * pl.runs_per_pass;
+        const uint32_t packed = pl.n_runs | (run_base << 15) | (xcd_runs << 31);
+        auto go = [&](auto kernel) {
+            kernel<<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, d_units, pl.n_po,
+                ps2, out_w, pl.tw, n_oct, oct_count, packed, out_begin, out_count,
+                pl.lv.cutoff, a2m1, cmin, d_counts ? theta_acc : theta_walk, core_thr, d_runs, d_counts);
+        };
+        if (d_counts) { if (early_records) go(ggx_oct_pairs<true, true>); else go(ggx_oct_pairs<true, false>); }
+        else          { if (early_records) go(ggx_oct_pairs<false, true>); else go(ggx_oct_pairs<false, false>); }
+        if (pass + 1 == pl.passes && ev1) (void)hipEventRecord(ev1, stream);
+        if (pl.reduce_groups > 1)
+            ggx_oct_reduce<<<dim3(small_blocks, 9, pl.passes > 1 ? pl.runs_per_pass / pl.per_group : pl.reduce_groups),
+                             GO_THREADS, 0, stream>>>(d_runs, pl.runs_per_pass, pl.per_group, run_base / pl.per_group, n_oct,
+                                                      d_units, oct_count, d_groups);
+    }
+    if (pl.reduce_groups > 1)
         ggx_oct_final<double><<<dim3(small_blocks, 8), GO_THREADS, 0, stream>>>(
             d_groups, pl.reduce_groups, out_w, pl.tw, d_units, n_oct, oct_count, out_begin, out_count, (float4*)d_out);
-    } else {
+    else
         ggx_oct_final<float><<<dim3(small_blocks, 8), GO_THREADS, 0, stream>>>(
             d_runs, pl.n_runs, out_w, pl.tw, d_units, n_oct, oct_count, out_begin, out_count, (float4*)d_out);
-    }
     return hipGetLastError();
 }
 

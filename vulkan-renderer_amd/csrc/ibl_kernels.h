@@ -20,6 +20,7 @@ struct Tuning {
     int ggx_xcd_slices = -1;       // octet GGX kernel: 1 / 0 force / forbid dealing runs to the XCDs (-1: automatic)
     int bake_rehearse_shards = 0;  // ibl_bake_*: > 1 makes one device play that many shards in turn (tests)
     float ggx_core = 2.0f;         // multiple of alpha^2 below which the reference's own denominator is repeated
+    int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
     float lamb_split_limit = 8.0f; // ... blocks whose texels cancel by more than this factor are redone with exact weights
 };
@@ -117,9 +118,12 @@ struct GgxOctPlan {
     uint32_t n_po;            // patch octets: 3 * (pw/2)^2
     uint32_t tw;              // edge of the output tile used for octet numbering
     uint32_t n_runs;          // partial sums per output octet; a wave walks one run
+    uint32_t passes;          // launches the runs are spread over (each reuses the same buffer of sums)
+    uint32_t runs_per_pass;
+    uint32_t per_group;       // consecutive runs per group of the two-stage sum
     uint32_t reduce_groups;   // > 1: the runs are summed in this many groups first
     uint32_t out_units;       // 64-octet units this call covers
-    size_t partial_bytes;     // [group][25][out_units*64] double (two-stage sums only) + [run][25][out_units*64] float
+    size_t partial_bytes;     // [group][25][out_units*64] double (two-stage sums only) + [run of one pass][25][out_units*64] float
     size_t rec_bytes;         // 7 float4 per input texel octet
     size_t pn_bytes;          // float4 per patch octet
 };
