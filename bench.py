@@ -63,8 +63,8 @@ FLOP_PER_LUT_SAMPLE = 40
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--input-downscale", type=int, default=1,
