@@ -2,6 +2,7 @@
 that fixes the number of runs per level) and grid orders.
 
     python tools/tune_ggx_runs.py [in_w levels waves...]   e.g.  2048 1,2 0 65536 262144 2e6
+    SHARD=r/n in the environment times shard r of n instead of the whole level.
 """
 import os
 import sys
@@ -29,7 +30,11 @@ def main():
                 ibl.set_tuning("ggx_xcd_slices", xcd)
                 ms = []
                 for _ in range(2):
-                    ibl.ggx_level(env, ow, m, mips, out=out)
+                    if os.environ.get("SHARD"):
+                        r, n = (int(v) for v in os.environ["SHARD"].split("/"))
+                        ibl.ggx_level_shard(env, ow, m, mips, r, n, out=out)
+                    else:
+                        ibl.ggx_level(env, ow, m, mips, out=out)
                     ms.append(ibl.last_kernel_ms())
                 print("level %d waves %-9g xcd %2d: %s ms" % (m, w, xcd, " ".join("%.2f" % x for x in ms)), flush=True)
 

@@ -628,13 +628,16 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const float a2m1 = pl.lv.alpha2 - 1.0f;
     const float core_thr = ggx_core_threshold(pl.lv.alpha2);
     // One wave per (unit, run).  Runs are dealt to the XCDs (see ggx_oct_pairs) when several
-    // runs would otherwise share each L2: the level is in the narrow-lobe regime, where a record
-    // feeds one weight evaluation and its load latency shows, or a run's records are more than
-    // half an L2 (2048 -> 1024 level, an eighth of the units: 150 -> 127 ms; 2048 -> 512 level
-    // at 96 runs: 1685 -> 1406 ms; wide-lobe levels with small runs lose 1-3 % with it).
+    // runs would otherwise share each L2: the call covers fewer units than the GPU has wave slots
+    // (a shard: an eighth of the 2048 -> 512 level 231 -> 181 ms, of 2048 -> 256 75 -> 62 ms), the
+    // level is in the narrow-lobe regime, where a record feeds one weight evaluation and its load
+    // latency shows, or a run's records are more than half an L2 (2048 -> 1024 level, an eighth of
+    // the units: 150 -> 127 ms).  Whole wide-lobe levels with small runs lose 1-3 % with it.  The
+    // order changes no sum.
     const double cone = 0.5 * (1.0 - fmax(0.0, 2.0 * (double)pl.lv.cutoff - 1.0));
     const double run_bytes = (double)pl.rec_bytes / (double)pl.n_runs;
-    uint32_t xcd_runs = (pl.runs_per_pass % 8 == 0 && (8.0 * cone < 1.5 || run_bytes > (double)(2u << 20))) ? 1u : 0u;
+    uint32_t xcd_runs = (pl.runs_per_pass % 8 == 0 &&
+                         (pl.out_units < 3072u || 8.0 * cone < 1.5 || run_bytes > (double)(2u << 20))) ? 1u : 0u;
     if (tuning().ggx_xcd_slices >= 0) xcd_runs = (tuning().ggx_xcd_slices != 0 && pl.runs_per_pass % 8 == 0) ? 1u : 0u;
     const dim3 grid(pl.runs_per_pass * pl.out_units);
     const uint32_t small_blocks = (pl.out_units * GO_UNIT + GO_THREADS - 1) / GO_THREADS;
