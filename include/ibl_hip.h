@@ -324,6 +324,11 @@ int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted)
  * With the kernels' instruction counts per record and per pattern this prices the arithmetic
  * actually executed.  0 for the general kernels. */
 int ibl_last_wave_work(uint64_t* wave_records, uint64_t* wave_patterns);
+/* Mirror-octet GGX kernel, counting on: the records of the patch octets its wavefronts walked,
+ * each counted once however many sign patterns were live there (wave_records of
+ * ibl_last_wave_work counts one per live pattern).  The quotient is the number of patterns a
+ * record is evaluated under at that level. */
+int ibl_last_wave_visits(uint64_t* wave_visits);
 /* Mirror-octet Lambertian, counting on.  The integral (cube.cpp:95-129) is evaluated with the
  * clamped cosine split into its even and odd halves, a quarter of the arithmetic; where a texel
  * comes out as the small difference of much larger halves (a texel in deep shadow of a very

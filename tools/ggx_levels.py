@@ -39,10 +39,10 @@ def main():
             flop = 30.0 * c["accepted"] + 8.0 * (c["tested"] - c["accepted"])
             lanes = c["tested"] / (512.0 * c["wave_records"]) if c["wave_records"] else float("nan")
             print("%-8s level %d out %4d r=%.3f cutoff=%.3f tested %.3e accepted %.3e  %.3f ms  %.1f Gtested/s  %.1f TFLOP/s(alg)"
-                  "  wave-records %.3e (lanes in use %.3f, %.1f ns each per SIMD)"
+                  "  wave-records %.3e (lanes in use %.3f, %.1f ns each per SIMD, %.2f patterns per record visited)"
                   % (mode, m, ow, p["roughness"], p["cutoff"], c["tested"], c["accepted"], best,
                      c["tested"] / best / 1e6, flop / best / 1e9, c["wave_records"], lanes,
-                     best * 1e6 * 1024 / max(c["wave_records"], 1)))
+                     best * 1e6 * 1024 / max(c["wave_records"], 1), c["wave_records"] / max(c.get("wave_visits", 0), 1)))
         print("%-8s chain kernel total %.3f ms" % (mode, total))
 
 

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "ibl_set_tuning": ([ctypes.c_char_p, ctypes.c_double], _int),
     "ibl_get_tuning": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)], _int),
     "ibl_last_exact_octets": ([ctypes.POINTER(_u64)], _int),
+    "ibl_last_wave_visits": ([ctypes.POINTER(_u64)], _int),
     "ibl_shutdown": ([], _int),
     "ibl_last_error": ([], ctypes.c_char_p),
     "ibl_device_count": ([], _int),
@@ -391,7 +392,10 @@ class Ibl:
         self._check(self.lib.ibl_last_counts(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         d, e = _u64(), _u64()
         self._check(self.lib.ibl_last_wave_work(ctypes.byref(d), ctypes.byref(e)))
-        return dict(patch_tests=a.value, tested=b.value, accepted=c.value, wave_records=d.value, wave_patterns=e.value)
+        f = _u64()
+        self._check(self.lib.ibl_last_wave_visits(ctypes.byref(f)))
+        return dict(patch_tests=a.value, tested=b.value, accepted=c.value, wave_records=d.value, wave_patterns=e.value,
+                    wave_visits=f.value)
 
     # -- host-buffer entry points ---------------------------------------------------------
     @staticmethod

@@ -56,7 +56,7 @@ struct State {
     bool timing = false, counting = false, timed_valid = false;
     Buffer a, b, pn, partial, counts, stage_in, stage_out, units;
     void* static_scratch = nullptr; // this device's copy of the file-scope scratch array (ibl_lambertian_static_dev)
-    uint64_t last_counts[6] = {0, 0, 0, 0, 0, 0};   // patch tests, texel tests, accepted, wave-records, wave-patterns, exact blocks
+    uint64_t last_counts[7] = {0, 0, 0, 0, 0, 0, 0};   // patch tests, texel tests, accepted, wave-records, wave-patterns, exact blocks
     int counts_pending = 0;          // 1: a GGX call's counters wait on the device, 2: a Lambertian call's
 };
 
@@ -396,13 +396,14 @@ int ibl_kernel_ms_back(uint32_t calls_back, float* ms) {
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
     if (int rc = check_ready()) return rc;
     if (S->counts_pending) {
-        unsigned long long h[6];
+        unsigned long long h[7];
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, S->counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
         if (S->counts_pending == 1) { S->last_counts[1] = h[1]; S->last_counts[2] = h[2]; }   // GGX: texel tests
         S->last_counts[3] = h[3];
         S->last_counts[4] = h[4];
         S->last_counts[5] = h[5];
+        S->last_counts[6] = h[6];
         S->counts_pending = 0;
     }
     if (patch_tests) *patch_tests = S->last_counts[0];
@@ -415,6 +416,12 @@ int ibl_last_wave_work(uint64_t* wave_records, uint64_t* wave_patterns) {
     if (int rc = ibl_last_counts(nullptr, nullptr, nullptr)) return rc;
     if (wave_records) *wave_records = S->last_counts[3];
     if (wave_patterns) *wave_patterns = S->last_counts[4];
+    return IBL_OK;
+}
+
+int ibl_last_wave_visits(uint64_t* wave_visits) {
+    if (int rc = ibl_last_counts(nullptr, nullptr, nullptr)) return rc;
+    if (wave_visits) *wave_visits = S->last_counts[6];
     return IBL_OK;
 }
 

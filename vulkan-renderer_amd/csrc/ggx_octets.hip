@@ -318,7 +318,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
 #pragma unroll
     for (int k = 0; k < GO_SUMS; k++) s_run[k][lane] = 0.0f;
     uint32_t n_accepted = 0;
-    unsigned long long tot_tested = 0, tot_accepted = 0, tot_walked = 0, tot_evaluated = 0;
+    unsigned long long tot_tested = 0, tot_accepted = 0, tot_walked = 0, tot_evaluated = 0, tot_visited = 0;
 
     // Three levels of sums, all in a fixed order: FP32 chunks of at most 256 terms in registers;
     // the run's FP32 running sums of its chunks (a few dozen) in LDS, indexed by output member;
@@ -403,6 +403,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
                     if (__any((lane_pass >> tau) & 1u)) wmask_v |= 1u << tau;
                 uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_v);    // the same in every lane
 
+                if (COUNT && wmask != 0u) tot_visited += ps2;
                 const float4* __restrict__ rp = rec + (size_t)po * ps2 * GO_REC;   // wave-uniform
                 // ---- one walk over the patch octet's records per live pattern
                 while (wmask) {
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
             atomicAdd(&counts[2], tot_accepted);
             atomicAdd(&counts[3], tot_walked);       // records this wave walked (64 lanes each, once per live pattern),
             atomicAdd(&counts[4], tot_evaluated);    // ... and those it evaluated past the cosine
+            atomicAdd(&counts[6], tot_visited);      // records of the patch octets it walked, once each
         }
     }
 }
