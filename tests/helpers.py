@@ -72,6 +72,58 @@ def write_png(path, rgba, color_type=6, filters=(0,)):
         f.write(data)
 
 
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
+
+
+def write_png_general(path, samples, depth, color_type, interlace=False, palette=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """Any PNG the format allows: samples (H, W, C) of raw sample values (C = 1, 2, 3 or 4 by colour
+    type), `depth` bits each, optionally Adam7-interlaced, with PLTE / tRNS chunks as given."""
+    import struct
+    import zlib
+    smp = np.asarray(samples, np.uint16)
+    h, w, ch = smp.shape
+    bpp = max(1, depth * ch // 8)
+
+    def pack_rows(sub):
+        """(ph, pw, C) samples -> filtered scanlines of one (sub-)image."""
+        ph, pw, _ = sub.shape
+        out, prev = [], None
+        for y in range(ph):
+            flat = sub[y].reshape(-1)
+            if depth == 16:
+                row = np.stack([flat >> 8, flat & 255], axis=1).reshape(-1).astype(np.int32)
+            elif depth == 8:
+                row = flat.astype(np.int32)
+            else:
+                bits = np.zeros(((len(flat) * depth + 7) // 8) * 8, np.uint8)
+                for b in range(depth):
+                    bits[np.arange(len(flat)) * depth + b] = (flat >> (depth - 1 - b)) & 1
+                row = np.packbits(bits).astype(np.int32)
+            if prev is None:
+                prev = np.zeros_like(row)
+            ft = filters[y % len(filters)]
+            out.append(bytes([ft]) + filter_row(row, prev, bpp, ft).tobytes())
+            prev = row
+        return b"".join(out)
+
+    if interlace:
+        raw = b"".join(pack_rows(smp[y0::dy, x0::dx]) for x0, y0, dx, dy in ADAM7
+                       if smp[y0::dy, x0::dx].shape[0] and smp[y0::dy, x0::dx].shape[1])
+    else:
+        raw = pack_rows(smp)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).reshape(-1)))
+    if trns is not None:
+        data += chunk(b"tRNS", bytes(trns))
+    data += chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(data)
+
+
 def read_png(path):
     """-> (H, W, 4) uint8 for the 8-bit RGBA files png_io writes."""
     import struct

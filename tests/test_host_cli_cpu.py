@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import read_png, write_png
+from helpers import read_png, write_png, write_png_general
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "vulkan-renderer_amd", "bin")
@@ -33,6 +33,55 @@ def test_png_io_roundtrip(tmp_path, color_type, filters):
     if color_type == 2:
         want[..., 3] = 255
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("color_type,depth", [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (3, 1), (3, 2), (3, 4),
+                                              (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)])
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_reader_takes_every_format_stb_takes(tmp_path, color_type, depth, interlace):
+    """cube.cpp:458 loads through stb_image with STBI_rgb_alpha: any bit depth, colour type and
+    Adam7.  Expected pixels by stb's rules: 16-bit samples keep their high byte, low-depth grey is
+    scaled to 0..255, a palette is looked up (with its tRNS alphas), a tRNS colour key turns the
+    matching pixels transparent."""
+    import importlib
+    png = importlib.import_module("vulkan_renderer_amd.pngio")
+    rng = np.random.default_rng(depth * 10 + color_type)
+    h, w = 13, 11                                           # not multiples of 8: short Adam7 passes
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color_type]
+    smp = rng.integers(0, 1 << depth, size=(h, w, ch), dtype=np.uint16)
+    palette = trns = None
+    if color_type == 3:
+        palette = rng.integers(0, 256, size=(1 << depth, 3), dtype=np.uint8)
+        trns = bytes(rng.integers(0, 256, size=min(1 << depth, 5), dtype=np.uint8))
+    elif color_type in (0, 2) and depth in (8, 16):
+        smp[3, 4] = smp[0, 0]                               # a colour key that two pixels match
+        trns = b"".join(int(v).to_bytes(2, "big") for v in smp[0, 0])
+    path = str(tmp_path / "x.png")
+    write_png_general(path, smp, depth, color_type, interlace, palette, trns)
+
+    def to8(v):
+        return (v >> 8).astype(np.uint8) if depth == 16 else (v * {1: 255, 2: 85, 4: 17, 8: 1}[depth]).astype(np.uint8)
+    want = np.zeros((h, w, 4), np.uint8)
+    if color_type == 3:
+        want[..., :3] = palette[smp[..., 0]]
+        alpha = np.full(1 << depth, 255, np.uint8)
+        alpha[:len(trns)] = np.frombuffer(trns, np.uint8)
+        want[..., 3] = alpha[smp[..., 0]]
+    else:
+        if color_type in (0, 4):
+            want[..., :3] = to8(smp[..., :1])
+        else:
+            want[..., :3] = to8(smp[..., :3])
+        if color_type in (4, 6):
+            want[..., 3] = to8(smp[..., -1])
+        elif trns is not None:
+            want[..., 3] = np.where((smp == smp[0, 0]).all(axis=-1), 0, 255)
+        else:
+            want[..., 3] = 255
+    np.testing.assert_array_equal(png.read_rgba8(path), want)
+    r = _run(ROUNDTRIP, path, str(tmp_path / "y.png"))      # and through the tool's own binary
+    assert r.returncode == 0, r.stderr
+    np.testing.assert_array_equal(read_png(str(tmp_path / "y.png")), want)
 
 
 def test_png_io_rejects_garbage(tmp_path):

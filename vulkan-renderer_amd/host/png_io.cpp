@@ -1,5 +1,5 @@
-// Minimal PNG reader/writer for the cube tool's boundary format: 8-bit,
-// non-interlaced images, returned/accepted as tightly packed RGBA8 rows.
+// PNG reader/writer for the cube tool's boundary format: reads any PNG bit depth and colour
+// type, Adam7 interlacing included, and returns tightly packed RGBA8 rows; writes RGBA8.
 // The reference goes through stb_image/stb_image_write for the same job
 // (cube.cpp:141,322,458); this is an independent implementation on top of zlib.
 #include "png_io.hpp"
@@ -99,6 +99,142 @@ bool deflate_parallel(const unsigned char* raw, size_t raw_size, std::vector<uns
     return true;
 }
 
+// Undoes the per-row filters of one (sub-)image: rows of 1 + stride bytes in, stride bytes out.
+// bpp: bytes per complete pixel, at least 1 (the filter's "left" distance).
+bool unfilter_rows(const unsigned char* raw, size_t stride, uint32_t h, size_t bpp, unsigned char* img, std::string& err) {
+    for (uint32_t y = 0; y < h; y++) {
+        const unsigned char* src = raw + (stride + 1) * y + 1;
+        unsigned char* cur = img + stride * y;
+        const unsigned char* up = y ? img + stride * (y - 1) : nullptr;
+        const int ft = src[-1];
+        switch (ft) {       // one loop per filter type: this runs over every byte of a strip that can hold hundreds of megabytes
+            case 0:
+                memcpy(cur, src, stride);
+                break;
+            case 1:
+                for (size_t i = 0; i < bpp && i < stride; i++) cur[i] = src[i];
+                for (size_t i = bpp; i < stride; i++) cur[i] = (unsigned char)(src[i] + cur[i - bpp]);
+                break;
+            case 2:
+                if (!up) memcpy(cur, src, stride);
+                else for (size_t i = 0; i < stride; i++) cur[i] = (unsigned char)(src[i] + up[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < stride; i++) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                    cur[i] = (unsigned char)(src[i] + (a + b) / 2);
+                }
+                break;
+            case 4:
+                for (size_t i = 0; i < stride; i++) {
+                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                    const int c = (up && i >= bpp) ? up[i - bpp] : 0;
+                    cur[i] = (unsigned char)(src[i] + paeth(a, b, c));
+                }
+                break;
+            default:
+                err = "bad PNG filter type";
+                return false;
+        }
+    }
+    return true;
+}
+
+// Everything the fast path below leaves out: 1/2/4/16-bit samples, Adam7 interlacing, colour keys.
+// Conversions to RGBA8 follow stb_image (the reader behind cube.cpp:458's STBI_rgb_alpha load):
+// 16-bit samples keep their high byte, low-depth grey is scaled to 0..255, a tRNS colour key makes
+// the matching pixels transparent.
+bool decode_general(const std::vector<unsigned char>& idat, uint32_t w, uint32_t h, int depth, int color, int interlace,
+                    int channels, const std::vector<unsigned char>& palette, const std::vector<unsigned char>& trns,
+                    std::vector<uint8_t>& rgba, std::string& err) {
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = { {0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2} };
+    static const Pass whole = {0, 0, 1, 1};
+    const Pass* passes = interlace ? adam7 : &whole;
+    const int n_passes = interlace ? 7 : 1;
+    const size_t bits = (size_t)depth * channels;
+    const size_t bpp = bits >= 8 ? bits / 8 : 1;
+    size_t total = 0;
+    for (int p = 0; p < n_passes; p++) {
+        const uint32_t pw = w > passes[p].x0 ? (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
+        const uint32_t ph = h > passes[p].y0 ? (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
+        if (pw && ph) total += (1 + ((size_t)pw * bits + 7) / 8) * ph;
+    }
+    std::vector<unsigned char> raw(total);
+    uLongf raw_len = (uLongf)raw.size();
+    int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
+    if (zrc != Z_OK || raw_len != raw.size()) { err = "PNG image data is corrupt"; return false; }
+
+    std::vector<uint16_t> px((size_t)w * h * channels);      // the samples as stored, before any conversion
+    size_t at = 0;
+    std::vector<unsigned char> img;
+    for (int p = 0; p < n_passes; p++) {
+        const uint32_t pw = w > passes[p].x0 ? (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
+        const uint32_t ph = h > passes[p].y0 ? (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
+        if (!pw || !ph) continue;
+        const size_t stride = ((size_t)pw * bits + 7) / 8;
+        img.resize(stride * ph);
+        if (!unfilter_rows(&raw[at], stride, ph, bpp, img.data(), err)) return false;
+        at += (stride + 1) * ph;
+        for (uint32_t py = 0; py < ph; py++) {
+            const unsigned char* row = &img[stride * py];
+            const uint32_t y = passes[p].y0 + py * passes[p].dy;
+            for (uint32_t pxi = 0; pxi < pw; pxi++) {
+                const uint32_t x = passes[p].x0 + pxi * passes[p].dx;
+                uint16_t* o = &px[((size_t)y * w + x) * channels];
+                for (int c = 0; c < channels; c++) {
+                    const size_t s = (size_t)pxi * channels + c;      // sample number in the row
+                    if (depth == 16) o[c] = (uint16_t)((row[2 * s] << 8) | row[2 * s + 1]);
+                    else if (depth == 8) o[c] = row[s];
+                    else {                                              // 1, 2, 4 bits, most significant first
+                        const size_t bit = s * depth;
+                        o[c] = (uint16_t)((row[bit / 8] >> (8 - depth - bit % 8)) & ((1 << depth) - 1));
+                    }
+                }
+            }
+        }
+    }
+
+    const int scale = depth == 1 ? 0xff : depth == 2 ? 0x55 : depth == 4 ? 0x11 : 1;     // low-depth grey to 0..255
+    auto to8 = [&](uint16_t v) -> uint8_t { return depth == 16 ? (uint8_t)(v >> 8) : (uint8_t)(v * (color == 3 ? 1 : scale)); };
+    const bool keyed = (color == 0 && trns.size() >= 2) || (color == 2 && trns.size() >= 6);
+    uint16_t key[3] = {0, 0, 0};
+    for (int c = 0; keyed && c < (color == 0 ? 1 : 3); c++) {
+        const uint16_t k16 = (uint16_t)((trns[2 * c] << 8) | trns[2 * c + 1]);
+        key[c] = depth == 16 ? k16 : (uint16_t)((k16 & 255) * scale);
+    }
+    rgba.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        const uint16_t* p = &px[i * channels];
+        uint8_t* o = &rgba[i * 4];
+        switch (color) {
+            case 0: {
+                o[0] = o[1] = o[2] = to8(p[0]);
+                const uint16_t cmp = depth == 16 ? p[0] : (uint16_t)o[0];
+                o[3] = (keyed && cmp == key[0]) ? 0 : 255;
+                break;
+            }
+            case 2: {
+                o[0] = to8(p[0]); o[1] = to8(p[1]); o[2] = to8(p[2]);
+                bool match = keyed;
+                for (int c = 0; match && c < 3; c++) match = (depth == 16 ? p[c] : (uint16_t)o[c]) == key[c];
+                o[3] = match ? 0 : 255;
+                break;
+            }
+            case 3: {
+                const size_t k = p[0];
+                if (k * 3 + 2 >= palette.size()) { err = "palette index out of range"; return false; }
+                o[0] = palette[k * 3]; o[1] = palette[k * 3 + 1]; o[2] = palette[k * 3 + 2];
+                o[3] = k < trns.size() ? trns[k] : 255;
+                break;
+            }
+            case 4: o[0] = o[1] = o[2] = to8(p[0]); o[3] = to8(p[1]); break;
+            default: o[0] = to8(p[0]); o[1] = to8(p[1]); o[2] = to8(p[2]); o[3] = to8(p[3]); break;
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba,
@@ -138,7 +274,6 @@ bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, 
         pos += 12 + (size_t)len;
     }
     if (w == 0 || h == 0) { err = "PNG has no IHDR"; return false; }
-    if (depth != 8 || interlace != 0) { err = "only 8-bit non-interlaced PNGs are supported"; return false; }
     int channels;
     switch (color) {
         case 0: channels = 1; break;
@@ -148,55 +283,28 @@ bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, 
         case 6: channels = 4; break;
         default: err = "unsupported PNG colour type"; return false;
     }
+    const bool depth_ok = color == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                        : color == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                     : (depth == 8 || depth == 16);
+    if (!depth_ok || interlace > 1) { err = "unsupported PNG bit depth or interlace method"; return false; }
+    if (depth != 8 || interlace != 0 || ((color == 0 || color == 2) && !trns.empty())) {
+        if (!decode_general(idat, w, h, depth, color, interlace, channels, palette, trns, rgba, err)) return false;
+        width = w;
+        height = h;
+        return true;
+    }
     const size_t stride = (size_t)w * channels;
     std::vector<unsigned char> raw((stride + 1) * h);
     uLongf raw_len = (uLongf)raw.size();
     int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
     if (zrc != Z_OK || raw_len != raw.size()) { err = "PNG image data is corrupt"; return false; }
 
-    // Undo the per-row filters (one loop per filter type: this runs over every byte of a
-    // strip that can hold hundreds of megabytes).
     // RGBA8 input (what the tool's own strips are) is unfiltered straight into the result.
     std::vector<unsigned char> other;
     if (color == 6) rgba.resize(stride * h);
     else other.resize(stride * h);
     unsigned char* const img = color == 6 ? rgba.data() : other.data();
-    const size_t bpp = (size_t)channels;
-    for (uint32_t y = 0; y < h; y++) {
-        const unsigned char* src = &raw[(stride + 1) * y] + 1;
-        unsigned char* cur = &img[stride * y];
-        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
-        const int ft = src[-1];
-        switch (ft) {
-            case 0:
-                memcpy(cur, src, stride);
-                break;
-            case 1:
-                for (size_t i = 0; i < bpp && i < stride; i++) cur[i] = src[i];
-                for (size_t i = bpp; i < stride; i++) cur[i] = (unsigned char)(src[i] + cur[i - bpp]);
-                break;
-            case 2:
-                if (!up) memcpy(cur, src, stride);
-                else for (size_t i = 0; i < stride; i++) cur[i] = (unsigned char)(src[i] + up[i]);
-                break;
-            case 3:
-                for (size_t i = 0; i < stride; i++) {
-                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
-                    cur[i] = (unsigned char)(src[i] + (a + b) / 2);
-                }
-                break;
-            case 4:
-                for (size_t i = 0; i < stride; i++) {
-                    const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
-                    const int c = (up && i >= bpp) ? up[i - bpp] : 0;
-                    cur[i] = (unsigned char)(src[i] + paeth(a, b, c));
-                }
-                break;
-            default:
-                err = "bad PNG filter type";
-                return false;
-        }
-    }
+    if (!unfilter_rows(raw.data(), stride, h, (size_t)channels, img, err)) return false;
 
     if (color != 6) rgba.resize((size_t)w * h * 4);
     for (size_t i = 0; color != 6 && i < (size_t)w * h; i++) {
