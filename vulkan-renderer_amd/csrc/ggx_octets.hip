@@ -579,7 +579,7 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
             if ((double)want > modest) want = modest >= 1.0 ? (uint32_t)modest : 1u;
             if (fit > (double)want) want = (uint32_t)fit;
         }
-        uint32_t max_runs = pl.n_po < 32767u ? pl.n_po : 32767u;     // at least one patch octet per run
+        uint32_t max_runs = pl.n_po < 32000u ? pl.n_po : 32000u;     // at least one patch octet per run; the run numbers travel in 15 bits
         if (max_runs == 0) max_runs = 1;
         uint32_t runs = want < 1 ? 1 : (want > max_runs ? max_runs : want);
         // What 4 GiB cannot hold at once is done in several launches over the same buffer, each
