@@ -792,3 +792,45 @@ def test_bake_on_several_shards_returns_the_same_bytes(ibl, orc):
     ibl.bake_rgbe(strip, input_downscale=2, cubemap_size=16)
     ibl.lib.ibl_set_progress(None, None)
     assert seen == [0, 1, 2]
+
+
+def test_timing_ring_and_knob_readback(ibl, orc):
+    """ibl_kernel_ms_back reads the kernel times of earlier timed calls (the benchmark queues its
+    steps and reads afterwards); ibl_get_tuning reads back what ibl_set_tuning / ibl_set_kernel_mode set."""
+    env, env_d = _env(ibl, orc, 64)
+    ibl.set_timing(True)
+    try:
+        for _ in range(3):
+            ibl.lambertian(env_d, 16)
+        ibl.ggx_level(env_d, 32, 1, 2)
+        last = ibl.last_kernel_ms()
+        assert last > 0 and ibl.kernel_ms_back(0) == last
+        earlier = [ibl.kernel_ms_back(k) for k in (1, 2, 3)]
+        assert all(0 < v < 50 for v in earlier)
+        with pytest.raises(vra.IblError):
+            ibl.kernel_ms_back(64)                         # the ring keeps 64
+    finally:
+        ibl.set_timing(False)
+    assert ibl.get_tuning("lamb_split") == 1 and ibl.get_tuning("general_only") == 0
+    ibl.set_tuning("lamb_split_limit", 4.0)
+    try:
+        assert ibl.get_tuning("lamb_split_limit") == 4.0
+        got = ibl.lambertian(env_d, 16).cpu().numpy()      # a stricter limit redoes more octets, same bars
+        _check_cube(orc, got, orc.lambertian(env, 16))
+    finally:
+        ibl.set_tuning("lamb_split_limit", 8.0)
+    with pytest.raises(vra.IblError):
+        ibl.get_tuning("no_such_knob")
+
+
+def test_ggx_counting_reports_visits(ibl, orc):
+    """wave_visits counts a walked record once, wave_records once per live sign pattern."""
+    env, env_d = _env(ibl, orc, 64)
+    ibl.set_counting(True)
+    try:
+        ibl.ggx_level(env_d, 16, 2, 2)
+        c = ibl.last_counts()
+    finally:
+        ibl.set_counting(False)
+    assert 0 < c["wave_visits"] <= c["wave_records"] <= 8 * c["wave_visits"]
+    assert c["wave_patterns"] <= c["wave_records"]
