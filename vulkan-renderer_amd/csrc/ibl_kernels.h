@@ -8,8 +8,9 @@
 namespace ibl {
 
 // Tuning and diagnostic knobs.  ibl_init reads them from the environment once
-// (IBL_NO_OCTETS, IBL_LAMB_P, IBL_LAMB_OCT_SLICES, IBL_LAMB_OCT_RUN, IBL_GGX_WAVES,
-// IBL_GGX_XCD_SLICES, IBL_GGX_CORE); no entry point looks at the environment afterwards.
+// (IBL_NO_OCTETS, IBL_LAMB_P, IBL_LAMB_OCT_SLICES, IBL_LAMB_OCT_RUN, IBL_LAMB_OCT_AFFINE,
+// IBL_LAMB_SPLIT, IBL_GGX_WAVES, IBL_GGX_XCD_SLICES, IBL_GGX_CORE); no entry point looks at the
+// environment afterwards.  ibl_set_tuning / ibl_get_tuning reach all of them by name.
 struct Tuning {
     bool no_octets = false;        // general kernels only
     int lamb_p = 0;                // general Lambertian kernel: output texels per thread (0: automatic)
