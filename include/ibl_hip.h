@@ -94,7 +94,12 @@ int ibl_ggx_level_params(uint32_t mip_level, uint32_t mip_levels, uint32_t in_w,
 
 /* ---- device-resident entry points ---------------------------------------- */
 
-/* integrateLambertian's texel loop, cube.cpp:95-129 (no encode, no file). */
+/* integrateLambertian's texel loop, cube.cpp:95-129 (no encode, no file).  On face sizes
+ * with exact mirror symmetry (every power of two) the clamped cosine of cube.cpp:112-115 is
+ * evaluated as the sum of its even and odd halves, and the octets of texels where those halves
+ * cancel by more than a factor 8 are recomputed pair by pair with the reference's own weights
+ * (see ibl_last_exact_octets): a texel is within ~1e-6 of the reference's double-accumulated
+ * sum either way, and exact zeros stay exact. */
 int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
                        uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
 
