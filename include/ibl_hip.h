@@ -97,8 +97,8 @@ int ibl_ggx_level_params(uint32_t mip_level, uint32_t mip_levels, uint32_t in_w,
 /* integrateLambertian's texel loop, cube.cpp:95-129 (no encode, no file).  On face sizes
  * with exact mirror symmetry (every power of two) the clamped cosine of cube.cpp:112-115 is
  * evaluated as the sum of its even and odd halves, and the octets of texels where those halves
- * cancel by more than a factor 8 are recomputed pair by pair with the reference's own weights
- * (see ibl_last_exact_octets): a texel is within ~1e-6 of the reference's double-accumulated
+ * cancel by more than a factor 16 are recomputed pair by pair with the reference's own weights
+ * (see ibl_last_exact_octets): a texel is within ~2e-6 of the reference's double-accumulated
  * sum either way, and exact zeros stay exact. */
 int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
                        uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
@@ -337,7 +337,7 @@ int ibl_last_wave_visits(uint64_t* wave_visits);
 /* Mirror-octet Lambertian, counting on.  The integral (cube.cpp:95-129) is evaluated with the
  * clamped cosine split into its even and odd halves, a quarter of the arithmetic; where a texel
  * comes out as the small difference of much larger halves (a texel in deep shadow of a very
- * bright light: cancellation above the knob "lamb_split_limit", 8), its octet (the texel and
+ * bright light: cancellation above the knob "lamb_split_limit", 16), its octet (the texel and
  * its 7 mirror images) is recomputed with the reference's own per-pair weights.  This returns
  * how many octets of the last call were.  ("lamb_split" 0 computes everything with those
  * weights.) */

@@ -236,7 +236,7 @@ def test_lambertian_split_falls_back_where_it_cancels(ibl, orc):
     difference of the halves; their octets must be found and redone with the reference's own
     weights -- and which ones are must not depend on how the cube is cut into calls."""
     env, _ = _env(ibl, orc, 64)
-    env[0, 20:24, 30:34, :3] = np.float32(1.5e3)             # a small bright light on +x: up to ~10x the sky's irradiance
+    env[0, 20:24, 30:34, :3] = np.float32(1.0e4)             # a small bright light on +x: up to ~35x the sky's irradiance
     env_d = _dev(ibl, env)
     want = orc.lambertian(env, 32)
     ibl.set_counting(True)
@@ -818,7 +818,7 @@ def test_timing_ring_and_knob_readback(ibl, orc):
         got = ibl.lambertian(env_d, 16).cpu().numpy()      # a stricter limit redoes more octets, same bars
         _check_cube(orc, got, orc.lambertian(env, 16))
     finally:
-        ibl.set_tuning("lamb_split_limit", 8.0)
+        ibl.set_tuning("lamb_split_limit", 16.0)
     with pytest.raises(vra.IblError):
         ibl.get_tuning("no_such_knob")
 

@@ -23,7 +23,7 @@ struct Tuning {
     float ggx_core = 2.0f;         // multiple of alpha^2 below which the reference's own denominator is repeated
     int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
-    float lamb_split_limit = 8.0f; // ... blocks whose texels cancel by more than this factor are redone with exact weights
+    float lamb_split_limit = 16.0f; // ... blocks whose texels cancel by more than this factor are redone with exact weights
 };
 Tuning& tuning();
 

@@ -25,7 +25,8 @@
 // mirror images and its antipode, its value is the small difference of the two halves, and their
 // FP32 rounding (about 1e-7 of the larger) no longer vanishes with it.  ls_final therefore measures
 // the cancellation of every texel it combines, (even + |odd|) / (even + odd), and marks the
-// output octets where it exceeds a limit (8: an error of at most ~1e-6 of the value); the marked
+// output octets where it exceeds a limit (16: measured error 1.2e-7 per unit of cancellation, so
+// at most ~2e-6 of the value); the marked
 // octets are then recomputed by lambertian_oct_pairs with the reference's own weights
 // (lambertian_oct_launch works on the 256-octet blocks that hold one, and stores the marked
 // octets only).  The mark depends on the octet's own 8 texels alone, never on the range or shard
