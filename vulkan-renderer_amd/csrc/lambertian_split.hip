@@ -201,8 +201,9 @@ __global__ __launch_bounds__(LS_THREADS, LS_MIN_WAVES) void ls_pairs(
     octet_decode(oo, hw, ls_tile_edge(hw), axis, oj, oi);
     // Members inside the requested (face, y, x) range decide whether the wave has anything to
     // store, and nothing else: a wave that runs adds for all its octets.
-    bool wanted = false;
-    if (valid) {
+    bool wanted = valid;
+    if (valid && !(out_begin == 0u && out_count >= 6u * out_size * out_size)) {      // (whole cubes and shards skip this)
+        wanted = false;
 #pragma unroll
         for (uint32_t s = 0; s < 8; s++) {
             Texel t = octet_member(axis, oj, oi, s, out_size, out_size);
