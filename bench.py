@@ -16,16 +16,18 @@ the cube on every rank; total work is fixed, so the scaling is "strong".
 
 Rank 0 prints ONE JSON line.  `value` is samples of the whole job per second.
 `roofline` prices the FP32 arithmetic the dominant kernel EXECUTED -- the records its
-wavefronts walked and the sign patterns they evaluated, counted by the kernel itself
-in an untimed pass, times the instruction counts of its inner loop -- over that
-kernel's mean duration (HIP events on its own stream) against the 157.3 TFLOP/s FP32
-vector peak; `algorithmic_equiv_tflops` prices the same launch at the flop count a
-pair-by-pair evaluation would need (the mirror-octet kernels share one dot product
-among 64 texel pairs, so this figure exceeds the peak).  `cpu_baseline` is the CPU
-oracle (a port of the reference's loop, recomputing the input direction per pair as
-the reference does) timed on a bounded sample of the same workload.  After the
-headline the run also times the GGX chains of configurations 3 and 5 (`c3_*`, `c5_*`
-keys), since the full bake spends 99 % of its time there.
+wavefronts walked (and, for the kernels that work pattern by pattern, the sign patterns
+they evaluated), counted by the kernel itself in an untimed pass, times the flop of the
+instructions its inner loop issues -- over that kernel's mean duration (HIP events on its
+own stream, read from the library's ring of event pairs after the timed loop) against the
+157.3 TFLOP/s FP32 vector peak; `algorithmic_equiv_tflops` prices the same launch at the
+flop count a pair-by-pair evaluation would need (the default Lambertian kernel needs 18
+vector instructions for 64 texel pairs, so this figure exceeds the peak many times over).
+`cpu_baseline` is the CPU oracle (a port of the reference's loop, recomputing the input
+direction per pair as the reference does) timed on a bounded sample of the same workload.
+After the headline the run also times the same workload on the exact-weights kernel
+(`c4_exact_weights_*`) and the GGX chains of configurations 3 and 5 (`c3_*`, `c5_*` keys),
+since the full bake spends 99 % of its time there.
 """
 import argparse
 import json
