@@ -92,6 +92,13 @@ uint32_t ibl_ggx_mip_levels(uint32_t top_w, uint32_t top_h, uint32_t min_size);
 int ibl_ggx_level_params(uint32_t mip_level, uint32_t mip_levels, uint32_t in_w, uint32_t in_h,
                          float* roughness, float* alpha2, float* cutoff, uint32_t* patch_size);
 
+/* How the mirror-octet kernel would run one whole GGX level (host arithmetic only, no device
+ * needed): the runs the level's input is dealt to (one partial sum per output texel and run),
+ * the launches they are spread over, and the bytes of workspace for the sums (never more than
+ * 4 GiB) and for the per-level records.  IBL_EINVAL for sizes the general kernel serves. */
+int ibl_ggx_level_plan(uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels, uint32_t* runs,
+                       uint32_t* passes, uint64_t* sums_bytes, uint64_t* records_bytes);
+
 /* ---- device-resident entry points ---------------------------------------- */
 
 /* integrateLambertian's texel loop, cube.cpp:95-129 (no encode, no file).  On face sizes

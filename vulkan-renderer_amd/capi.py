@@ -81,6 +81,8 @@ _SIGNATURES = {
     "ibl_last_kernel_ms": ([ctypes.POINTER(ctypes.c_float)], _int),
     "ibl_set_counting": ([_int], _int),
     "ibl_last_counts": ([ctypes.POINTER(_u64)] * 3, _int),
+    "ibl_ggx_level_plan": ([_u32, _u32, _u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_u64),
+                            ctypes.POINTER(_u64)], _int),
     "ibl_kernel_ms_back": ([_u32, ctypes.POINTER(ctypes.c_float)], _int),
     "ibl_last_wave_work": ([ctypes.POINTER(_u64)] * 2, _int),
 }
@@ -107,6 +109,18 @@ def shard_indices(kind, in_w, out_w, mip, mips, shard, n_shards):
     if rc != 0:
         raise IblError(rc, lib.ibl_last_error().decode())
     return idx
+
+
+def ggx_level_plan(in_w, out_w, mip, mips):
+    """Runs, launches and workspace bytes of one whole GGX level on the mirror-octet kernel (host
+    arithmetic of the library: no GPU needed)."""
+    lib = load_library()
+    runs, passes, sums, recs = _u32(), _u32(), _u64(), _u64()
+    rc = lib.ibl_ggx_level_plan(in_w, out_w, mip, mips, ctypes.byref(runs), ctypes.byref(passes), ctypes.byref(sums),
+                                ctypes.byref(recs))
+    if rc != 0:
+        raise IblError(rc, lib.ibl_last_error().decode())
+    return dict(runs=runs.value, passes=passes.value, sums_bytes=sums.value, records_bytes=recs.value)
 
 
 def exported_symbols():

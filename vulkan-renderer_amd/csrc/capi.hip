@@ -358,6 +358,24 @@ int ibl_ggx_level_params(uint32_t mip_level, uint32_t mip_levels, uint32_t in_w,
     return IBL_OK;
 }
 
+int ibl_ggx_level_plan(uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels, uint32_t* runs,
+                       uint32_t* passes, uint64_t* sums_bytes, uint64_t* records_bytes) {
+    read_tuning_once();
+    if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
+        return fail(IBL_EINVAL, "ggx level %u of %u is out of range", mip_level, mip_levels);
+    if (in_w < 16 || out_w == 0) return fail(IBL_EINVAL, "ggx_level_plan: faces %u -> %u", in_w, out_w);
+    const ibl::GgxLevel lv = ibl::ggx_level_params(mip_level, mip_levels, in_w, in_w);
+    if (g_tuning.no_octets || !ibl::ggx_octets_eligible(in_w, out_w, lv.patch))
+        return fail(IBL_EINVAL, "ggx_level_plan: faces %u -> %u are served by the general kernel", in_w, out_w);
+    const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
+    const ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, (n_oct + ibl::GGX_OCT_UNIT - 1) / ibl::GGX_OCT_UNIT);
+    if (runs) *runs = pl.n_runs;
+    if (passes) *passes = pl.passes;
+    if (sums_bytes) *sums_bytes = pl.partial_bytes;
+    if (records_bytes) *records_bytes = pl.rec_bytes + pl.pn_bytes;
+    return IBL_OK;
+}
+
 int ibl_set_timing(int enabled) {
     if (int rc = check_ready()) return rc;
     S->timing = enabled != 0;

@@ -570,7 +570,6 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
         const double rec_total = (double)pl.n_po * ps * ps * GO_REC * sizeof(float4);
         const double per_run = (double)units_level * GO_UNIT * GO_SUMS * sizeof(float);
         const double fit = ceil(rec_total / (double)(4u << 20));
-        const double afford = floor((double)(4ull << 30) / per_run);
         // ... and the partial sums should not be many times the bytes the level has to move anyway
         // (32 per input texel, 16 per output texel): at most 8 times those.
         const double algorithmic = 32.0 * pl.n_po * ps * ps * 8.0 + 16.0 * n_oct_level * 8.0;
@@ -582,27 +581,50 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
         uint32_t max_runs = pl.n_po < 32000u ? pl.n_po : 32000u;     // at least one patch octet per run; the run numbers travel in 15 bits
         if (max_runs == 0) max_runs = 1;
         uint32_t runs = want < 1 ? 1 : (want > max_runs ? max_runs : want);
-        // What 4 GiB cannot hold at once is done in several launches over the same buffer, each
-        // followed by its groups' sums (2048 -> 1024: 96 runs as 2 x 48; the same bits as one launch).
-        uint32_t passes = (uint32_t)ceil((double)runs / (afford >= 1.0 ? afford : 1.0));
-        if (passes < 1) passes = 1;
-        // a multiple of 8 per launch, so that the 8 XCDs can own equal shares of the runs (see ggx_oct_pairs)
-        uint32_t per_pass = (runs + passes - 1) / passes;
-        if (passes > 1) per_pass = (per_pass + 7) / 8 * 8;
-        else if (per_pass >= 16) per_pass = per_pass / 8 * 8;
-        while (passes > 1 && (double)per_pass > afford) { passes++; per_pass = ((runs + passes - 1) / passes + 7) / 8 * 8; }
-        pl.passes = passes;
-        pl.runs_per_pass = per_pass;
-        pl.n_runs = per_pass * passes;
+        // The sums of one launch's runs (FP32) and of the groups of runs (FP64) together stay below
+        // 4 GiB for the whole level.  What that cannot hold at once is launched in several passes
+        // over the same buffer, each followed by its groups' sums (2048 -> 1024: 96 runs as 3 x 32,
+        // 3.0 GB; the same bits as one launch would give).  A group never spans two launches, and a
+        // launch has a multiple of 8 runs, so that the 8 XCDs can own equal shares of them (see
+        // ggx_oct_pairs).  Levels too large even for 8 runs at a time (8192 -> 4096: 1.3 GB per run)
+        // take what fits in one launch.
+        const double elems = (double)units_level * GO_UNIT * GO_SUMS;
+        const double budget = (double)(4ull << 30);
+        auto groups_of = [](uint32_t n) { uint32_t g = n > 64 ? (n + 31) / 32 : 1; return g > 64 ? 64u : g; };
+        auto single_fits = [&](uint32_t n) {
+            const uint32_t g = groups_of(n);
+            return elems * ((double)n * sizeof(float) + (g > 1 ? (double)g * sizeof(double) : 0.0)) <= budget;
+        };
+        pl.passes = 0;
+        if (single_fits(runs)) {
+            pl.passes = 1;
+            pl.runs_per_pass = runs >= 16 ? runs / 8 * 8 : runs;
+        } else {
+            for (uint32_t passes = 2; passes <= 64 && pl.passes == 0; passes++) {
+                const uint32_t per_pass = ((runs + passes - 1) / passes + 7) / 8 * 8;
+                uint32_t per_group = 8;
+                for (uint32_t g = 32; g >= 8; g--)
+                    if (per_pass % g == 0) { per_group = g; break; }
+                const uint32_t groups = passes * (per_pass / per_group);
+                if (elems * ((double)per_pass * sizeof(float) + (double)groups * sizeof(double)) <= budget) {
+                    pl.passes = passes;
+                    pl.runs_per_pass = per_pass;
+                    pl.per_group = per_group;
+                }
+            }
+            if (pl.passes == 0) {               // not even 8 runs at a time: one launch of what fits
+                uint32_t n = runs;
+                while (n > 1 && !single_fits(n)) n--;
+                pl.passes = 1;
+                pl.runs_per_pass = n >= 16 ? n / 8 * 8 : n;
+            }
+        }
+        pl.n_runs = pl.runs_per_pass * pl.passes;
     }
     pl.out_units = n_units;
     const uint32_t oct_count = pl.out_units * GO_UNIT;
-    // many runs are summed in two stages (fixed grouping, so still one summation order); a group
-    // never spans two launches
+    // many runs are summed in two stages (fixed grouping, so still one summation order)
     if (pl.passes > 1) {
-        pl.per_group = pl.runs_per_pass;
-        for (uint32_t g = 32; g >= 8; g--)
-            if (pl.runs_per_pass % g == 0) { pl.per_group = g; break; }
         pl.reduce_groups = pl.n_runs / pl.per_group;
     } else {
         pl.reduce_groups = pl.n_runs > 64 ? (pl.n_runs + 31) / 32 : 1;
