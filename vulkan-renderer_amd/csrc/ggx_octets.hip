@@ -135,6 +135,89 @@ __device__ __forceinline__ void go_unpack(const GoRec& s, float (&r)[28]) {
     for (int i = 0; i < 8; i++) r[20 + i] = __uint_as_float(s.c[i]);
 }
 
+// ---- matrix form of the records (ggx_oct_pairs<.., MX = true>) ----------------------------------
+// The sums of a walk are a small dense product: (64 output octets x records) weights times (records
+// x 25) record columns -- the 24 member radiances and |w|^-3.  The matrix form feeds it to
+// v_mfma_f32_32x32x16_bf16 with every FP32 factor cut into two bf16 pieces (nearest-even upper
+// piece, then the nearest-even bf16 of the exact remainder: 16 significant bits, relative error
+// <= 2^-18) and the three partial products hi*hi, hi*mid, mid*hi added in the FP32 accumulators.
+// A weight's two pieces multiply all 25 columns of its record, so what the cut does to a weight
+// cancels in the quotient sum(L W) / sum(W) (cube.cpp:305) to first order; what it does to a record
+// column is a fixed 2^-18 perturbation of that input texel.
+// Layout: float4 (canonical unit direction, |w|^-3) per record, patch-octet-major like the vector
+// form; then per 16 consecutive records two 1 KB tiles (upper pieces, lower pieces) in the B-operand
+// order of the instruction: lane l holds column l % 32 of records 8 (l / 32) + 0..7 as 8 bf16.
+typedef float go_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 go_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int GO_MX_GROUP = 16;                       // records per matrix instruction
+constexpr int GO_MX_REC_BYTES = 16 + 2 * 64;          // direction + two pieces of 32 columns
+
+__device__ __forceinline__ uint32_t go_bf16_bits(float x) {          // nearest even; finite x
+    const uint32_t b = __float_as_uint(x);
+    return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+}
+
+__global__ __launch_bounds__(256) void ggx_mx_prep(const float4* __restrict__ env, uint32_t w, uint32_t ps,
+                                                    uint32_t n_rec, float4* __restrict__ dirs, go_u32x4* __restrict__ tiles) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t grp = t / 64, l = t % 64;
+    if (grp * GO_MX_GROUP >= n_rec) return;
+    const uint32_t col = l & 31u, half = l >> 5;
+    const uint32_t ps2 = ps * ps, hpw = (w / ps) / 2;
+    uint32_t hi[8], mid[8];
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) {
+        const uint32_t k = grp * GO_MX_GROUP + half * 8 + e;
+        const uint32_t po = k / ps2, sub = k - po * ps2;
+        const uint32_t sy = sub / ps, sx = sub - sy * ps;
+        const uint32_t axis = po / (hpw * hpw);
+        const uint32_t prem = po - axis * (hpw * hpw);
+        const uint32_t pj = prem / hpw, pi = prem - pj * hpw;
+        const uint32_t j = pj * ps + sy, i = pi * ps + sx;
+        Texel c = octet_member(axis, j, i, 0, w, w);
+        F3 d = ref_normal_from(c.face, c.x, c.y, w, w);     // all components > 0
+        float l2 = ref_dot(d, d);
+        float s = 1.0f / (l2 * sqrtf(l2));
+        float v = 0.0f;
+        if (col < 24u) {
+            const uint32_t m = col / 3u, ch = col - 3u * m;
+            Texel tx = octet_member(axis, j, i, m, w, w);
+            const float4 L = env[(tx.face * w + tx.y) * w + tx.x];
+            v = (ch == 0u ? L.x : ch == 1u ? L.y : L.z) * s;
+        } else if (col == 24u) {
+            v = s;
+        }
+        hi[e] = go_bf16_bits(v);
+        mid[e] = go_bf16_bits(v - __uint_as_float(hi[e] << 16));
+        if (col == 0u) {
+            F3 u = ref_normalize(d);
+            dirs[k] = make_float4(u.x, u.y, u.z, s);
+        }
+    }
+    go_u32x4 a, b;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { a[q] = hi[2 * q] | (hi[2 * q + 1] << 16); b[q] = mid[2 * q] | (mid[2 * q + 1] << 16); }
+    tiles[(size_t)(grp * 2) * 64 + l] = a;
+    tiles[(size_t)(grp * 2 + 1) * 64 + l] = b;
+}
+
+// Four records' directions (float4 each) in scalar registers (matrix form).
+struct GoDir4 { go_u32x16 v; };
+__device__ __forceinline__ void go_dir_load(GoDir4& r, const float4* __restrict__ p) {
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(r.v) : "s"(p));
+}
+__device__ __forceinline__ void go_dir_wait(GoDir4& r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.v));
+}
+// bf16(a) in the lower half, bf16(b) in the upper half, nearest even (v_cvt_pk_bf16_f32; as a
+// conversion the compiler sees, so that it keeps the wait states of the lane swap that reads it).
+__device__ __forceinline__ uint32_t go_pack_bf16(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = { a, b };
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
 struct GoConst {
     float cutoff, om_a2, cmin;
     float core_thr;   // below this denominator the reference's own rounding is reproduced (0: never)
@@ -147,8 +230,8 @@ struct GoConst {
 // acc[si] to output member si ^ tau when it folds the chunk into the running sums.
 // CORE: some lane of the wave may be inside the lobe core for this patch (see below).
 template <bool COUNT, bool CORE>
-__device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr, float a2p, const GoConst& k,
-                                        const F3& nt, float (&acc)[8][3], float& accw, uint32_t& n_acc) {
+__device__ __forceinline__ float go_weight(float c, float ux, float uy, float uz, float thr, float a2p, const GoConst& k,
+                                           const F3& nt, uint32_t& n_acc) {
     float u = fmaf(-0.5f, c, 0.5f);
     float t = 1.0f - u;
     float sq = __builtin_amdgcn_sqrtf(t);
@@ -164,7 +247,7 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
     if (CORE) {
         const bool core = d < k.core_thr;
         if (__any(core)) {
-            F3 uu = { r[0], r[1], r[2] };
+            F3 uu = { ux, uy, uz };
             float den = ref_ggx_denominator(uu, nt, -k.om_a2);
             d = core ? den : d;
         }
@@ -184,6 +267,13 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
         float qd = sub_clamp01(t, thr) * __builtin_amdgcn_rcpf(d);
         f = mul_clamp01(c, sq) * (qd * qd);
     }
+    return f;
+}
+
+template <bool COUNT, bool CORE>
+__device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr, float a2p, const GoConst& k,
+                                        const F3& nt, float (&acc)[8][3], float& accw, uint32_t& n_acc) {
+    const float f = go_weight<COUNT, CORE>(c, r[0], r[1], r[2], thr, a2p, k, nt, n_acc);
     accw = fmaf(f, r[3], accw);
 #pragma unroll
     for (int si = 0; si < 8; si++) {
@@ -206,8 +296,16 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
 // that straddle the window's edge, and at these levels a third of the texels it then tests fail
 // (cube.cpp:271); a wave's 64 directions lie within a few degrees, so they mostly fail together.
 // Narrow lobes accept 99 % of what the patch test lets through and skip the test.
-template <bool COUNT, bool EARLY>
-__global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs(
+// MX: the sums of a walk go through the matrix pipe (see ggx_mx_prep for the operand format and
+// what it costs in accuracy); rec then points at the records' directions, followed by their tiles.
+#ifndef GO_MX_MIN_WAVES
+#define GO_MX_MIN_WAVES 4          // 128 registers: no spills (5: 96 and 308 bytes of scratch, 2.5 % slower)
+#endif
+#ifndef GO_MX_TERMS
+#define GO_MX_TERMS 3                    // 3: hi*hi + hi*mid + mid*hi;  4: + mid*mid
+#endif
+template <bool COUNT, bool EARLY, bool MX = false>
+__global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_WAVES)) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn, const uint32_t* __restrict__ units,
     uint32_t n_po, uint32_t ps2,
     uint32_t out_w, uint32_t tw, uint32_t n_oct, uint32_t oct_local,
@@ -215,8 +313,9 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
     float cutoff, float a2m1, float cmin, float theta_acc, float core_thr,
     float* __restrict__ partial, unsigned long long* __restrict__ counts) {
     static_assert(GO_WG == 64, "one wave per workgroup: the grid below is counted in waves");
-    // the run's running sums: [sum][lane]
-    __shared__ float s_run[GO_SUMS][GO_WG];
+    static_assert(!(MX && (COUNT || EARLY)), "the matrix form neither counts nor drops records");
+    // the run's running sums: [sum][lane] (matrix form: rows padded, its fold walks down the sums)
+    __shared__ float s_run[GO_SUMS][MX ? GO_WG + 1 : GO_WG];
     const uint32_t lane = threadIdx.x & 63;
     // Workgroups go to the 8 XCDs round-robin by their linear index, and every XCD has its own
     // L2.  Plain order is (run, unit) with units fastest: the waves in flight then belong to one
@@ -315,6 +414,13 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
     for (int m = 0; m < 8; m++)
 #pragma unroll
         for (int k = 0; k < 3; k++) acc[m][k] = 0.0f;
+    // Matrix form: the chunk sums are two 32 x 32 accumulator tiles (output octets 0-31 and 32-63 of
+    // the wave x record columns); this lane holds column lane % 32 of both, rows (i % 4) + 8 (i / 4) +
+    // 4 (lane / 32) in element i.
+    go_f32x16 mx0, mx1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { mx0[i] = 0.0f; mx1[i] = 0.0f; }
+    const uint32_t mx_col = lane & 31u, mx_member = mx_col / 3u, mx_chan = mx_col - 3u * mx_member;
 #pragma unroll
     for (int k = 0; k < GO_SUMS; k++) s_run[k][lane] = 0.0f;
     uint32_t n_accepted = 0;
@@ -341,6 +447,22 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
         accw = 0.0f;
     };
     auto flush = [&](uint32_t tau) __attribute__((always_inline)) {          // wave-uniform
+        if constexpr (MX) {
+            // column mx_col of the tiles is sum mx_chan of input member mx_member (24: the weight sum)
+            if (mx_col < 25u) {
+                const uint32_t oc = mx_col < 24u ? (mx_member ^ tau) * 3u + mx_chan : 24u;
+                float* p = &s_run[oc][4u * (lane >> 5)];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int row = (i & 3) + 8 * (i >> 2);
+                    p[row] += mx0[i];
+                    p[32 + row] += mx1[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) { mx0[i] = 0.0f; mx1[i] = 0.0f; }
+            return;
+        }
         switch (tau) {
             case 0: fold(std::integral_constant<int, 0>{}); break;
             case 1: fold(std::integral_constant<int, 1>{}); break;
@@ -450,8 +572,80 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : GO_MIN_WAVES) void ggx_oct_pairs
                         }
                         go_rec_wait(ra);       // nothing of this walk is in flight when it ends
                     };
-                    if (core_near) walk(std::true_type{});
-                    else walk(std::false_type{});
+                    auto walk_mx = [&](auto core_c) __attribute__((always_inline)) {
+                        constexpr bool CORE = decltype(core_c)::value;
+                        const float4* __restrict__ dp = rec + (size_t)po * ps2;                 // wave-uniform
+                        const go_u32x4* __restrict__ tp = (const go_u32x4*)(rec + (size_t)n_po * ps2)
+                                                          + (size_t)po * (ps2 / GO_MX_GROUP) * 128 + lane;
+                        GoDir4 da, db;
+                        uint32_t none = 0;
+                        // four records: weights, cut into their two bf16 pieces, two records to a register
+                        auto quad = [&](const GoDir4& src, uint32_t& h0, uint32_t& h1, uint32_t& m0, uint32_t& m1)
+                                        __attribute__((always_inline)) {
+                            float f[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float ux = __uint_as_float(src.v[4 * e]), uy = __uint_as_float(src.v[4 * e + 1]),
+                                            uz = __uint_as_float(src.v[4 * e + 2]);
+                                float c = nt.x * ux;
+                                c = fmaf(nt.y, uy, c);
+                                c = fmaf(nt.z, uz, c);
+                                f[e] = go_weight<false, CORE>(c, ux, uy, uz, thr, a2p, kc, nt, none);
+                            }
+                            h0 = go_pack_bf16(f[0], f[1]);
+                            h1 = go_pack_bf16(f[2], f[3]);
+                            m0 = go_pack_bf16(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u));
+                            m1 = go_pack_bf16(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
+                        };
+                        go_dir_load(da, dp);
+                        for (uint32_t g = 0; g < ps2; g += GO_MX_GROUP) {
+                            const go_u32x4 b_hi = tp[0], b_mid = tp[64];
+                            tp += 128;
+                            uint32_t ah[8], am[8];
+                            go_dir_wait(da);
+                            go_dir_load(db, dp + g + 4);
+                            quad(da, ah[0], ah[1], am[0], am[1]);
+                            go_dir_wait(db);
+                            go_dir_load(da, dp + g + 8);
+                            quad(db, ah[2], ah[3], am[2], am[3]);
+                            go_dir_wait(da);
+                            go_dir_load(db, dp + g + 12);
+                            quad(da, ah[4], ah[5], am[4], am[5]);
+                            go_dir_wait(db);
+                            go_dir_load(da, dp + min(g + 16, ps2 - 4));
+                            quad(db, ah[6], ah[7], am[6], am[7]);
+                            // A operands: rows are the output octets, so the upper lanes' records 0-7 and the lower
+                            // lanes' records 8-15 change places (lanes 32-63 of the first register with lanes 0-31
+                            // of the second)
+                            go_u32x4 a0h, a1h, a0m, a1m;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                auto sh = __builtin_amdgcn_permlane32_swap(ah[i], ah[4 + i], false, false);
+                                a0h[i] = sh[0]; a1h[i] = sh[1];
+                                auto sm = __builtin_amdgcn_permlane32_swap(am[i], am[4 + i], false, false);
+                                a0m[i] = sm[0]; a1m[i] = sm[1];
+                            }
+                            auto bf = [](const go_u32x4& v) { return __builtin_bit_cast(go_bf16x8, v); };
+                            mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0m), bf(b_hi), mx0, 0, 0, 0);
+                            mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1m), bf(b_hi), mx1, 0, 0, 0);
+                            if (GO_MX_TERMS >= 4) {
+                                mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0m), bf(b_mid), mx0, 0, 0, 0);
+                                mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1m), bf(b_mid), mx1, 0, 0, 0);
+                            }
+                            mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_mid), mx0, 0, 0, 0);
+                            mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_mid), mx1, 0, 0, 0);
+                            mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_hi), mx0, 0, 0, 0);
+                            mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_hi), mx1, 0, 0, 0);
+                        }
+                        go_dir_wait(da);       // nothing of this walk is in flight when it ends
+                    };
+                    if constexpr (MX) {
+                        if (core_near) walk_mx(std::true_type{});
+                        else walk_mx(std::false_type{});
+                    } else {
+                        if (core_near) walk(std::true_type{});
+                        else walk(std::false_type{});
+                    }
                     if (COUNT) { tot_accepted += (unsigned long long)n_accepted * 8ull; n_accepted = 0; tot_walked += ps2; }
                 }
             }
@@ -554,6 +748,11 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     // traffic is kept to a few per cent of the estimated run time).
     const double cmin = fmax(0.0, 2.0 * (double)pl.lv.cutoff - 1.0);
     const double cone = 0.5 * (1.0 - cmin);                              // accepted share of the sphere
+    // The matrix form takes whole groups of 16 records (inputs of 64 x 64 and more).  It cannot drop
+    // single records after their cosine as EARLY does at wide lobes, and is still the faster one there
+    // (2048 -> 256: 323 ms against 462; 512 -> 64: 1.64 against 2.16).
+    pl.matrix = tuning().ggx_matrix != 0 && (ps * ps) % GO_MX_GROUP == 0;
+    const size_t rec_each = pl.matrix ? (size_t)GO_MX_REC_BYTES : GO_REC * sizeof(float4);
     const double wave_records = (double)n_oct_level / 64.0 * (double)pl.n_po * ps * ps * 8.0 * cone;
     const double seconds = wave_records * 70e-9 / 1024.0;                // ~70 ns per wave, record and pattern per SIMD
     double waves = 0.04 * seconds * 1.5e12 / (64.0 * GO_SUMS * 4.0);
@@ -567,7 +766,7 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     // 1004 ms.  So at most 4 MiB of records per run; the partial sums that costs are kept below
     // 4 GiB by launching the runs in several passes (below).
     {
-        const double rec_total = (double)pl.n_po * ps * ps * GO_REC * sizeof(float4);
+        const double rec_total = (double)pl.n_po * ps * ps * (double)rec_each;
         const double per_run = (double)units_level * GO_UNIT * GO_SUMS * sizeof(float);
         const double fit = ceil(rec_total / (double)(4u << 20));
         // ... and the partial sums should not be many times the bytes the level has to move anyway
@@ -633,7 +832,8 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     }
     const uint32_t stage2 = pl.reduce_groups > 1 ? pl.reduce_groups : 0;
     pl.partial_bytes = (size_t)GO_SUMS * oct_count * (pl.runs_per_pass * sizeof(float) + stage2 * sizeof(double));
-    pl.rec_bytes = (size_t)pl.n_po * ps * ps * GO_REC * sizeof(float4);
+    // (the counting variant walks the vector form's records: room for the larger of the two)
+    pl.rec_bytes = (size_t)pl.n_po * ps * ps * (pl.matrix ? (size_t)GO_MX_REC_BYTES : GO_REC * sizeof(float4));
     pl.pn_bytes = (size_t)pl.n_po * sizeof(float4);
     return pl;
 }
@@ -644,7 +844,12 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
                           hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t ps = pl.lv.patch, ps2 = ps * ps, pw = in_w / ps;
     const uint32_t n_rec = pl.n_po * ps2;
-    ggx_oct_prep<<<(n_rec + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, ps, n_rec, (float4*)d_rec);
+    const bool matrix = pl.matrix && !d_counts;
+    if (matrix)
+        ggx_mx_prep<<<(n_rec / GO_MX_GROUP * 64 + 255) / 256, 256, 0, stream>>>(
+            (const float4*)d_env, in_w, ps, n_rec, (float4*)d_rec, (go_u32x4*)((float4*)d_rec + n_rec));
+    else
+        ggx_oct_prep<<<(n_rec + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, ps, n_rec, (float4*)d_rec);
     ggx_oct_prep_patches<<<(pl.n_po + 255) / 256, 256, 0, stream>>>(pw, pl.n_po, (float4*)d_pn);
     const double cut = (double)pl.lv.cutoff;
     const float cmin = (float)fmax(0.0, 2.0 * cut - 1.0);
@@ -682,7 +887,7 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     // branch: worth it only while other waves fill that time (512 -> 16: 2304 waves, 0.37 -> 0.54 ms
     // with it).  It changes no sum -- a skipped record has weight 0 in every lane -- so the choice
     // may depend on the call's size.
-    const bool early_records = early && (uint64_t)pl.runs_per_pass * pl.out_units >= 24576u;
+    const bool early_records = early && !matrix && (uint64_t)pl.runs_per_pass * pl.out_units >= 24576u;
     if (ev0) (void)hipEventRecord(ev0, stream);
     for (uint32_t pass = 0; pass < pl.passes; pass++) {
         const uint32_t run_base = pass * pl.runs_per_pass;
@@ -693,6 +898,7 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
                 pl.lv.cutoff, a2m1, cmin, d_counts ? theta_acc : theta_walk, core_thr, d_runs, d_counts);
         };
         if (d_counts) { if (early_records) go(ggx_oct_pairs<true, true>); else go(ggx_oct_pairs<true, false>); }
+        else if (matrix) go(ggx_oct_pairs<false, false, true>);
         else          { if (early_records) go(ggx_oct_pairs<false, true>); else go(ggx_oct_pairs<false, false>); }
         if (pass + 1 == pl.passes && ev1) (void)hipEventRecord(ev1, stream);
         if (pl.reduce_groups > 1)

@@ -96,13 +96,13 @@ __device__ __forceinline__ F3 ref_out_normal(uint32_t o, uint32_t w, uint32_t h)
 }
 
 // v_fma_f32 with the clamp output modifier: max(0, min(1, a*b+c)) in one VALU
-// issue.  Every dot product clamped this way in these kernels is between a unit
+// issue (the compiler folds a median with 0 and 1 into the modifier of the instruction that
+// produces its operand, and keeps the instruction's wait states after a v_sqrt / v_rcp operand,
+// which it does not see through an asm statement).  Every dot product clamped this way in these kernels is between a unit
 // vector and a vector of length <= 1, so the upper bound never binds and this is
 // the max(0, .) of cube.cpp:112-115 for free.
 __device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
-    float r;
-    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __builtin_amdgcn_fmed3f(__builtin_fmaf(a, b, c), 0.0f, 1.0f);
 }
 
 // ---- mirror octets -------------------------------------------------------------
@@ -170,23 +170,15 @@ __host__ __device__ inline bool octet_unit_in_range(uint32_t u, uint32_t unit, u
 
 // v_add_f32 / v_sub_f32 with the clamp output modifier (result clamped to [0, 1]).
 __device__ __forceinline__ float add_clamp01(float a, float b) {
-    float r;
-    asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return __builtin_amdgcn_fmed3f(a + b, 0.0f, 1.0f);
 }
 __device__ __forceinline__ float sub_clamp01(float a, float b) {
-    float r;
-    asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return __builtin_amdgcn_fmed3f(a - b, 0.0f, 1.0f);
 }
 __device__ __forceinline__ float mul_clamp01(float a, float b) {
-    float r;
-    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return __builtin_amdgcn_fmed3f(a * b, 0.0f, 1.0f);
 }
 // max(0, min(1, -a - b))
 __device__ __forceinline__ float neg_sub_clamp01(float a, float b) {
-    float r;
-    asm("v_sub_f32_e64 %0, -%1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return __builtin_amdgcn_fmed3f(-a - b, 0.0f, 1.0f);
 }

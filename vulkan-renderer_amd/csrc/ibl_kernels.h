@@ -9,7 +9,7 @@ namespace ibl {
 
 // Tuning and diagnostic knobs.  ibl_init reads them from the environment once
 // (IBL_NO_OCTETS, IBL_LAMB_P, IBL_LAMB_OCT_SLICES, IBL_LAMB_OCT_RUN, IBL_LAMB_OCT_AFFINE,
-// IBL_LAMB_SPLIT, IBL_GGX_WAVES, IBL_GGX_XCD_SLICES, IBL_GGX_CORE); no entry point looks at the
+// IBL_LAMB_SPLIT, IBL_GGX_WAVES, IBL_GGX_XCD_SLICES, IBL_GGX_CORE, IBL_GGX_MATRIX); no entry point looks at the
 // environment afterwards.  ibl_set_tuning / ibl_get_tuning reach all of them by name.
 struct Tuning {
     bool no_octets = false;        // general kernels only
@@ -23,6 +23,7 @@ struct Tuning {
     float ggx_core = 2.0f;         // multiple of alpha^2 below which the reference's own denominator is repeated
     int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
+    int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
     float lamb_split_limit = 16.0f; // ... blocks whose texels cancel by more than this factor are redone with exact weights
 };
 Tuning& tuning();
@@ -125,7 +126,8 @@ struct GgxOctPlan {
     uint32_t reduce_groups;   // > 1: the runs are summed in this many groups first
     uint32_t out_units;       // 64-octet units this call covers
     size_t partial_bytes;     // [group][25][out_units*64] double (two-stage sums only) + [run of one pass][25][out_units*64] float
-    size_t rec_bytes;         // 7 float4 per input texel octet
+    bool matrix;              // the level's sums go through the matrix pipe (records in their matrix form)
+    size_t rec_bytes;         // 7 float4 per input texel octet (matrix form: 144 bytes)
     size_t pn_bytes;          // float4 per patch octet
 };
 bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
