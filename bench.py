@@ -57,6 +57,13 @@ LAMB_SPLIT_FLOP_PER_LANE_RECORD = 38
 # FMAs (48): 62.
 GGX_FLOP_PER_LANE_WALKED = 5
 GGX_FLOP_PER_LANE_EVALUATED = 62
+# Matrix form of ggx_oct_pairs (the default for inputs of 64 x 64 and more): the vector pipe keeps the
+# cosine (5) and the weight (12), and cuts the weight into two bf16 pieces (2 conversions, 1 fused
+# multiply-subtract: 4): 16 per record evaluated.  The 25 sums are v_mfma_f32_32x32x16_bf16: 3 partial
+# products x 32 columns x 2 flop = 192 per lane and record on the matrix pipe (peak 2.5 PFLOP/s dense).
+GGX_MX_FLOP_PER_LANE_EVALUATED = 16
+GGX_MX_MATRIX_FLOP_PER_LANE_RECORD = 192
+BF16_MATRIX_PEAK_TFLOPS = 2500.0
 FLOP_PER_GGX_ACCEPTED = 30          # pair by pair
 FLOP_PER_GGX_REJECTED = 8
 FLOP_PER_LUT_SAMPLE = 40
@@ -171,10 +178,18 @@ class Workload:
             lv1 = self.levels[0]
             self.flop_per_launch = (FLOP_PER_GGX_ACCEPTED * lv1["my_accepted"]
                                     + FLOP_PER_GGX_REJECTED * (lv1["my_tested"] - lv1["my_accepted"]))
-            if lv1["my_wave_records"]:
+            # the matrix form takes whole groups of 16 records: patches of 4 x 4 texels and more
+            self.matrix = (ibl.get_tuning("ggx_matrix") != 0 and self.env_w >= 64 and not args.ggx_samples
+                           and bool(lv1["my_wave_records"]))
+            self.matrix_flop_per_launch = None
+            if lv1["my_wave_records"] and self.matrix:
+                self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED + GGX_MX_FLOP_PER_LANE_EVALUATED) \
+                    * lv1["my_wave_records"]
+                self.matrix_flop_per_launch = 64.0 * GGX_MX_MATRIX_FLOP_PER_LANE_RECORD * lv1["my_wave_records"]
+            elif lv1["my_wave_records"]:
                 self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED * lv1["my_wave_records"]
                                                         + GGX_FLOP_PER_LANE_EVALUATED * lv1["my_wave_evaluated"])
-            self.kernel = "ggx_oct_pairs (level 1)"
+            self.kernel = "ggx_oct_pairs%s (level 1)" % (", matrix form" if self.matrix else "")
             self.desc = ("C%s: GGX prefilter chain of a %dx%d/face environment, %d levels, --input-downscale %d; "
                          "samples = in-patch texel tests (%.3g tested, %.3g accepted)"
                          % (name[1], self.in_w, self.in_w, self.mips, self.down, tested, accepted))
@@ -390,6 +405,12 @@ def chain_extra(name, args, ibl, rank, world, dist, torch, steps, cpu_seconds):
         out[name + "_level1_executed_tflops"] = round(tf, 2)
         out[name + "_level1_frac_of_fp32_peak"] = round(tf / FP32_VECTOR_PEAK_TFLOPS, 4)
         out[name + "_level1_algorithmic_equiv_tflops"] = round(wl.flop_per_launch / (kernel_ms * 1e-3) / 1e12, 2)
+        if getattr(wl, "matrix_flop_per_launch", None):
+            # the kernel's time is the sum of its two pipes' shares (measured: they do not overlap on a SIMD)
+            mtf = wl.matrix_flop_per_launch / (kernel_ms * 1e-3) / 1e12
+            out[name + "_level1_matrix_bf16_tflops"] = round(mtf, 1)
+            out[name + "_level1_frac_of_bf16_matrix_peak"] = round(mtf / BF16_MATRIX_PEAK_TFLOPS, 4)
+            out[name + "_level1_both_pipes_frac"] = round(tf / FP32_VECTOR_PEAK_TFLOPS + mtf / BF16_MATRIX_PEAK_TFLOPS, 4)
     if world == 1 and cpu_seconds > 0:
         cb = cpu_baseline(wl, cpu_seconds)
         out[name + "_cpu_port_gsamples"] = round(cb["value"], 4)
@@ -475,6 +496,12 @@ def main():
         }
         if getattr(wl, "patterns_per_record", None):
             line["roofline"]["sign_patterns_per_record"] = round(wl.patterns_per_record, 3)
+        if getattr(wl, "matrix_flop_per_launch", None) and kernel_ms > 0:
+            # the sums of this kernel run on the matrix pipe; its time is the sum of the two pipes' shares
+            mtf = wl.matrix_flop_per_launch / (kernel_ms * 1e-3) / 1e12
+            line["roofline"]["matrix_bf16_tflops"] = round(mtf, 1)
+            line["roofline"]["frac_of_bf16_matrix_peak"] = round(mtf / BF16_MATRIX_PEAK_TFLOPS, 4)
+            line["roofline"]["both_pipes_frac"] = round(achieved / FP32_VECTOR_PEAK_TFLOPS + mtf / BF16_MATRIX_PEAK_TFLOPS, 4)
         if getattr(wl, "exact_octets", None) is not None:
             # output octets whose even and odd halves cancel too far and were redone with exact weights
             line["roofline"]["exact_weight_octets"] = wl.exact_octets

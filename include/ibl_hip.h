@@ -135,7 +135,15 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
 
 /* One iteration of integrateGGX's level loop, cube.cpp:152-309 (no encode, no
  * file).  Rejects min(in_w,in_h) < 16, where the reference divides by a zero
- * patch size (cube.cpp:175,182). */
+ * patch size (cube.cpp:175,182).
+ * Arithmetic: the weights of cube.cpp:274-290 are evaluated in FP32 as the reference does; the
+ * sums of cube.cpp:292-295 are FP32 over at most 256 terms, then FP32 over a run of those, then
+ * FP64.  On mirror-symmetric face sizes with an input of 64 x 64 and more the products
+ * weight x radiance of those first sums are formed on the matrix pipe from two bf16 pieces of each
+ * factor (16 significant bits; knob "ggx_matrix", 1 by default, 0 keeps them in FP32 on the vector
+ * pipe): measured against the FP32 form <= 1e-6 on environments where more than a handful of
+ * texels lie under a lobe (99.99 % of the RGBE texels identical), and mean 1.6e-6 / at most 2e-5
+ * for a single lit texel in a black environment, where nothing averages the cuts. */
 int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
                       uint32_t mip_level, uint32_t mip_levels,
                       uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
@@ -309,7 +317,9 @@ int ibl_png_filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t* r
 int ibl_set_kernel_mode(int general_only);
 /* Launch-shape knobs of the kernels (slice counts, grid orders; the names are the
  * library's own, the tools under tools/ use them).  They change speed only, except
- * the slice counts, which fix the order of the sums and with it the last bits. */
+ * the slice counts, which fix the order of the sums and with it the last bits, and
+ * "lamb_split" / "ggx_matrix", which choose between two forms of the arithmetic (see
+ * ibl_lambertian_dev and ibl_ggx_level_dev). */
 int ibl_set_tuning(const char* name, double value);
 /* The current value of a knob ("general_only" reads back ibl_set_kernel_mode). */
 int ibl_get_tuning(const char* name, double* value);

@@ -29,7 +29,9 @@
 //       the patch's records, reading them with wave-uniform (scalar) loads
 //       (one walk per live pattern).  FP32 sums in registers cover up to 256 records; each is
 //       then added to the run's FP32 running sums, which live in LDS.  No scratch memory, no
-//       barriers.
+//       barriers.  Default for inputs of 64 x 64 and more (matrix form, ggx_mx_prep): the lanes
+//       still evaluate the weights, 16 records at a time, and the 25 sums of those records are
+//       three v_mfma_f32_32x32x16_bf16 per half of the wave on two bf16 pieces of every factor.
 //   ggx_oct_reduce / ggx_oct_final   per output octet: the runs summed in a fixed two-stage
 //       order in FP64, divided, scattered to the member texels that lie in the requested
 //       (face, y, x) range.
