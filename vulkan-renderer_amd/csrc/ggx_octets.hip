@@ -593,6 +593,10 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                                 c = fmaf(nt.y, uy, c);
                                 c = fmaf(nt.z, uz, c);
                                 f[e] = go_weight<false, CORE>(c, ux, uy, uz, thr, a2p, kc, nt, none);
+                                // (left alone the compiler evaluates cosine, u and d of all 16 records and their
+                                // exact denominators first and keeps them for the weights: 40 registers more than
+                                // the rest of the kernel needs; the empty statement ends a record before the next)
+                                if (CORE) asm volatile("" : "+v"(f[e]));
                             }
                             h0 = go_pack_bf16(f[0], f[1]);
                             h1 = go_pack_bf16(f[2], f[3]);
