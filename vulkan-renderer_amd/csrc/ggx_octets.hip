@@ -146,8 +146,9 @@ __device__ __forceinline__ void go_unpack(const GoRec& s, float (&r)[28]) {
 // A weight's two pieces multiply all 25 columns of its record, so what the cut does to a weight
 // cancels in the quotient sum(L W) / sum(W) (cube.cpp:305) to first order; what it does to a record
 // column is a fixed 2^-18 perturbation of that input texel.
-// Layout: float4 (canonical unit direction, |w|^-3) per record, patch-octet-major like the vector
-// form; then per 16 consecutive records two 1 KB tiles (upper pieces, lower pieces) in the B-operand
+// Layout: canonical unit direction and |w|^-3 of the records, patch-octet-major like the vector
+// form, four records to a 64-byte block (x0-3, y0-3, z0-3, |w|^-3 0-3: neighbouring records' components
+// are then scalar register pairs for packed instructions); then per 16 consecutive records two 1 KB tiles (upper pieces, lower pieces) in the B-operand
 // order of the instruction: lane l holds column l % 32 of records 8 (l / 32) + 0..7 as 8 bf16.
 typedef float go_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 go_bf16x8 __attribute__((ext_vector_type(8)));
@@ -191,9 +192,10 @@ __global__ __launch_bounds__(256) void ggx_mx_prep(const float4* __restrict__ en
         }
         hi[e] = go_bf16_bits(v);
         mid[e] = go_bf16_bits(v - __uint_as_float(hi[e] << 16));
-        if (col == 0u) {
+        if (col == 0u) {      // four records to a 64-byte block: their x, their y, their z, their |w|^-3
             F3 u = ref_normalize(d);
-            dirs[k] = make_float4(u.x, u.y, u.z, s);
+            float* blk = (float*)(dirs + (k & ~3u));
+            blk[k & 3u] = u.x; blk[4 + (k & 3u)] = u.y; blk[8 + (k & 3u)] = u.z; blk[12 + (k & 3u)] = s;
         }
     }
     go_u32x4 a, b;
@@ -270,6 +272,23 @@ __device__ __forceinline__ float go_weight(float c, float ux, float uy, float uz
         f = mul_clamp01(c, sq) * (qd * qd);
     }
     return f;
+}
+
+// Two records at once (matrix form, patches away from the lobe core): the same operations in the
+// same order as go_weight, the multiplies, adds and FMAs as v_pk_*_f32 on the pair.
+typedef float go_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ go_f32x2 go_weight_pair(go_f32x2 c, float thr, float a2p, const GoConst& k) {
+    const go_f32x2 half = { 0.5f, 0.5f }, mhalf = { -0.5f, -0.5f }, one = { 1.0f, 1.0f };
+    const go_f32x2 om = { k.om_a2, k.om_a2 }, a2 = { a2p, a2p };
+    go_f32x2 u = __builtin_elementwise_fma(mhalf, c, half);
+    go_f32x2 t = one - u;
+    go_f32x2 d = __builtin_elementwise_fma(u, om, a2);
+    const go_f32x2 sq = { __builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y) };
+    const go_f32x2 rd = { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y) };
+    const go_f32x2 cw = { sub_clamp01(t.x, thr), sub_clamp01(t.y, thr) };
+    go_f32x2 qd = cw * rd;
+    const go_f32x2 m = { mul_clamp01(c.x, sq.x), mul_clamp01(c.y, sq.y) };
+    return m * (qd * qd);
 }
 
 template <bool COUNT, bool CORE>
@@ -580,23 +599,40 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                         const go_u32x4* __restrict__ tp = (const go_u32x4*)(rec + (size_t)n_po * ps2)
                                                           + (size_t)po * (ps2 / GO_MX_GROUP) * 128 + lane;
                         GoDir4 da, db;
-                        uint32_t none = 0;
                         // four records: weights, cut into their two bf16 pieces, two records to a register
                         auto quad = [&](const GoDir4& src, uint32_t& h0, uint32_t& h1, uint32_t& m0, uint32_t& m1)
                                         __attribute__((always_inline)) {
                             float f[4];
+                            if constexpr (!CORE) {
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const float ux = __uint_as_float(src.v[4 * e]), uy = __uint_as_float(src.v[4 * e + 1]),
-                                            uz = __uint_as_float(src.v[4 * e + 2]);
-                                float c = nt.x * ux;
-                                c = fmaf(nt.y, uy, c);
-                                c = fmaf(nt.z, uz, c);
-                                f[e] = go_weight<false, CORE>(c, ux, uy, uz, thr, a2p, kc, nt, none);
-                                // (left alone the compiler evaluates cosine, u and d of all 16 records and their
-                                // exact denominators first and keeps them for the weights: 40 registers more than
-                                // the rest of the kernel needs; the empty statement ends a record before the next)
-                                if (CORE) asm volatile("" : "+v"(f[e]));
+                                for (int e = 0; e < 4; e += 2) {
+                                    const go_f32x2 ux = { __uint_as_float(src.v[e]), __uint_as_float(src.v[e + 1]) };
+                                    const go_f32x2 uy = { __uint_as_float(src.v[4 + e]), __uint_as_float(src.v[5 + e]) };
+                                    const go_f32x2 uz = { __uint_as_float(src.v[8 + e]), __uint_as_float(src.v[9 + e]) };
+                                    const go_f32x2 nx = { nt.x, nt.x }, ny = { nt.y, nt.y }, nz = { nt.z, nt.z };
+                                    go_f32x2 c = nx * ux;
+                                    c = __builtin_elementwise_fma(ny, uy, c);
+                                    c = __builtin_elementwise_fma(nz, uz, c);
+                                    const go_f32x2 w = go_weight_pair(c, thr, a2p, kc);
+                                    f[e] = w.x; f[e + 1] = w.y;
+                                }
+                            } else {
+                                // near the lobe core: record by record (two exact denominators side by side cost
+                                // more registers than 4 waves per SIMD leave)
+                                uint32_t none = 0;
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const float ux = __uint_as_float(src.v[e]), uy = __uint_as_float(src.v[4 + e]),
+                                                uz = __uint_as_float(src.v[8 + e]);
+                                    float c = nt.x * ux;
+                                    c = fmaf(nt.y, uy, c);
+                                    c = fmaf(nt.z, uz, c);
+                                    f[e] = go_weight<false, true>(c, ux, uy, uz, thr, a2p, kc, nt, none);
+                                    // (left alone the compiler evaluates cosine, u and d of all 16 records and their
+                                    // exact denominators first and keeps them for the weights: 40 registers more than
+                                    // the rest of the kernel needs; the empty statement ends a record before the next)
+                                    asm volatile("" : "+v"(f[e]));
+                                }
                             }
                             h0 = go_pack_bf16(f[0], f[1]);
                             h1 = go_pack_bf16(f[2], f[3]);
