@@ -9,7 +9,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline $*"
+STEPS=${STEPS:-3}; WARMUP=${WARMUP:-1}     # (short launches need more of them to reach the steady clock)
+ARGS="$ROOT/bench.py --workload $WL --steps $STEPS --warmup $WARMUP --no-cpu-baseline $*"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}stats -o r -- python3 $ARGS > $OUT/${TAG}stats.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/${TAG}pmc1 -o r -- python3 $ARGS > $OUT/${TAG}pmc1.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}pmc2 -o r -- python3 $ARGS > $OUT/${TAG}pmc2.log 2>&1

@@ -17,9 +17,10 @@
 //       w^[0] = |v0| + |v4| + |v1| + |v2|      w^[3] = |v0| + |v4| - |v1| - |v2|
 //       w^[5] = |v0| - |v4| - |v1| + |v2|      w^[6] = |v0| - |v4| + |v1| - |v2|
 //   (v0 = a+b+c > 0, v4 = a+b-c, v2 = a-b+c, v1 = -a+b+c).  The records hold L^[k] for those four
-//   k (ls_prep), so one record costs 12 vector instructions for the coefficients and 6 packed
-//   multiply-adds per output octet (ls_pairs), where lambertian_oct_pairs spends 11 and then
-//   13 more for every sign pattern that is live in the wave (4.2 on average).
+//   k (ls_prep), so one record costs 12 vector operations for the coefficients and 6 packed
+//   multiply-adds per output octet (ls_pairs; issued for two records at a time, 8 of the 12 as
+//   4 packed instructions), where lambertian_oct_pairs spends 11 and then 13 more for every sign
+//   pattern that is live in the wave (4.2 on average).
 //
 // What this costs is exactness of the zero: where an output texel sees much less light than its
 // mirror images and its antipode, its value is the small difference of the two halves, and their
@@ -34,13 +35,15 @@
 //
 // Kernel plan
 //   ls_prep      one thread per input octet: the record (folded direction g, L^[0,3,5,6] x RGB,
-//                64 bytes), and the octet's share of the first moment, summed per workgroup in FP64.
+//                64 bytes; two records share a 128-byte block laid out for packed instructions),
+//                and the octet's share of the first moment, summed per workgroup in FP64.
 //   ls_moment    one workgroup: the workgroups' shares in a fixed order.
 //   ls_pairs     grid = (blocks of 256 output octets) x (input slices), as lambertian_oct_pairs;
 //                every wave works alone on 64 output octets and walks the slice's records with
-//                wave-uniform (scalar) loads, two register sets, the next record in flight while
-//                one is evaluated: no LDS, no barrier.  FP32 sums over 128 records, FP64 over the
-//                slice, stored as FP32 slice sums.
+//                wave-uniform (scalar) loads, two register sets, the next block of two records in
+//                flight while one is evaluated: no LDS, no barrier.  FP32 sums over 128 records
+//                (blue: the even and the odd records apart), FP64 over the slice, stored as FP32
+//                slice sums.
 //   ls_reduce / ls_final   runs of 8 slices, then all runs, in FP64; inverse transform, the odd
 //                half added, scaled, cancellation measured, stored where the range asks.
 #include "ibl_device.h"
@@ -101,10 +104,24 @@ __global__ __launch_bounds__(256) void ls_prep(const float4* __restrict__ env, u
                 for (uint32_t s = 0; s < 8; s++) v += ls_sign(ks[q], s) * L[s][ch];
                 e[q * 3 + ch] = (float)v;
             }
-        rec[(size_t)k * LS_REC + 0] = make_float4(g[0], g[1], g[2], 0.0f);
-        rec[(size_t)k * LS_REC + 1] = make_float4(e[0], e[1], e[2], e[3]);
-        rec[(size_t)k * LS_REC + 2] = make_float4(e[4], e[5], e[6], e[7]);
-        rec[(size_t)k * LS_REC + 3] = make_float4(e[8], e[9], e[10], e[11]);
+        // Two records to a 128-byte block, laid out for packed instructions on the pair:
+        //   0-5    g.x of both, g.y of both, g.z of both        6-7  unused
+        //   8+6q   (red, green) of coefficient q of the first record, the same of the second,
+        //          blue of both                                  (q = 0..3)
+        float* blk = (float*)(rec + (size_t)(k >> 1) * (2 * LS_REC));
+        const uint32_t h = k & 1u;
+        blk[h] = g[0]; blk[2 + h] = g[1]; blk[4 + h] = g[2]; blk[6 + h] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            blk[8 + 6 * q + 2 * h] = e[3 * q];
+            blk[8 + 6 * q + 2 * h + 1] = e[3 * q + 1];
+            blk[8 + 6 * q + 4 + h] = e[3 * q + 2];
+        }
+        if (k + 1 == n_oct && h == 0u) {         // an odd count: the block's second record is all zero
+            blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 0.0f; blk[7] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { blk[8 + 6 * q + 2] = 0.0f; blk[8 + 6 * q + 3] = 0.0f; blk[8 + 6 * q + 5] = 0.0f; }
+        }
         // first moment: member s points to (+-gx, +-gy, +-gz), minus where its bit is set
 #pragma unroll
         for (int ax = 0; ax < 3; ax++)
@@ -157,12 +174,12 @@ __global__ __launch_bounds__(256) void ls_moment(const double* __restrict__ part
 // address); ls_rec_wait ties the registers to the wait, so that no use can be scheduled in front
 // of it.
 typedef uint32_t ls_u32x16 __attribute__((ext_vector_type(16)));
-struct LsRec { ls_u32x16 v; };
+struct LsRec { ls_u32x16 a, b; };        // a block of two records (see ls_prep)
 __device__ __forceinline__ void ls_rec_load(LsRec& r, const float4* __restrict__ p) {
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(r.v) : "s"(p));
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(r.a), "=&s"(r.b) : "s"(p));
 }
 __device__ __forceinline__ void ls_rec_wait(LsRec& r) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.v));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b));
 }
 
 #ifndef LS_MIN_WAVES
@@ -217,65 +234,76 @@ __global__ __launch_bounds__(LS_THREADS, LS_MIN_WAVES) void ls_pairs(
     const F3 n = ref_normalize(ref_normal_from(c.face, c.x, c.y, out_size, out_size));   // cube.cpp:97
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    // sums in record order: (0r,0g) (0b,3r) (3g,3b) (5r,5g) (5b,6r) (6g,6b)
-    f32x2 acc[6];
+    // FP32 sums of a chunk, per coefficient: (red, green), and blue of the even and of the odd records
+    f32x2 rg[4], bb[4];
     double dacc[LS_SUMS];
 #pragma unroll
-    for (int q = 0; q < 6; q++) acc[q] = f32x2{0.0f, 0.0f};
+    for (int q = 0; q < 4; q++) { rg[q] = f32x2{0.0f, 0.0f}; bb[q] = f32x2{0.0f, 0.0f}; }
 #pragma unroll
     for (int q = 0; q < LS_SUMS; q++) dacc[q] = 0.0;
 
-    const uint32_t in0 = slice * slice_len;
+    const uint32_t in0 = slice * slice_len;                          // even: slices are whole tiles
     const uint32_t in1 = min(n_oct_in, in0 + slice_len);
     const uint32_t n_rec = in1 - in0;                                // >= 1
-    const float4* __restrict__ rp = rec + (size_t)in0 * LS_REC;      // wave-uniform
+    const uint32_t n_blk = (n_rec + 1u) / 2u;                        // (an odd end is padded with a zero record)
+    const float4* __restrict__ rp = rec + (size_t)(in0 / 2u) * (2 * LS_REC);      // wave-uniform
 
+    const f32x2 nx = { n.x, n.x }, ny = { n.y, n.y }, nz = { n.z, n.z };
     auto eval = [&](const LsRec& r) __attribute__((always_inline)) {
+        // Two records at once, one in each half of a packed instruction.
         // |x+y| + |x-y| = 2 max(|x|, |y|) and |x+y| - |x-y| = 2 sign(xy) min(|x|, |y|) give the four
         // coefficients, halved, from a+b, a-b and c with a max, a min, a max and a median:
         //   (|v0| + |v4|)/2 = max(a+b, c)      (|v0| - |v4|)/2 = min(a+b, c)
         //   (|v2| + |v1|)/2 = max(c, |a-b|)    (|v2| - |v1|)/2 = median(a-b, -c, c)
-        const float a = n.x * __uint_as_float(r.v[0]);
-        const float s1 = fmaf(n.y, __uint_as_float(r.v[1]), a), s2 = fmaf(-n.y, __uint_as_float(r.v[1]), a);
-        const float cc = n.z * __uint_as_float(r.v[2]);
-        const float p = __builtin_fmaxf(s1, cc), q = __builtin_fminf(s1, cc);
-        const float t = __builtin_fmaxf(cc, fabsf(s2)), u = __builtin_amdgcn_fmed3f(s2, -cc, cc);
-        const f32x2 w03 = f32x2{p + t, p - t};       // w^[0]/2, w^[3]/2
-        const f32x2 w56 = f32x2{q + u, q - u};       // w^[5]/2, w^[6]/2
-        // Packed multiply-adds with the record pair straight from scalar registers and the weight
-        // halves picked by operand selects (w.xx, w, w.yy): written out, because the compiler copies
-        // a weight into a second register pair for every .yy.
+        auto fpair = [&](int at) __attribute__((always_inline)) { return f32x2{__uint_as_float(r.a[at]), __uint_as_float(r.a[at + 1])}; };
+        const f32x2 gx = fpair(0), gy = fpair(2), gz = fpair(4);
+        const f32x2 a = nx * gx;
+        const f32x2 s1 = __builtin_elementwise_fma(ny, gy, a), s2 = __builtin_elementwise_fma(-ny, gy, a);
+        const f32x2 cc = nz * gz;
+        const f32x2 p = { __builtin_fmaxf(s1.x, cc.x), __builtin_fmaxf(s1.y, cc.y) };
+        const f32x2 q = { __builtin_fminf(s1.x, cc.x), __builtin_fminf(s1.y, cc.y) };
+        const f32x2 t = { __builtin_fmaxf(cc.x, fabsf(s2.x)), __builtin_fmaxf(cc.y, fabsf(s2.y)) };
+        const f32x2 u = { __builtin_amdgcn_fmed3f(s2.x, -cc.x, cc.x), __builtin_amdgcn_fmed3f(s2.y, -cc.y, cc.y) };
+        const f32x2 w[4] = { p + t, p - t, q + u, q - u };          // w^[0]/2, w^[3]/2, w^[5]/2, w^[6]/2 of both records
+        // Packed multiply-adds with the record data straight from scalar registers and the record's
+        // weight picked by operand selects (written out: the compiler copies a weight into a second
+        // register pair for every broadcast).
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        auto pair = [&](int at) __attribute__((always_inline)) { return u32x2{r.v[at], r.v[at + 1]}; };
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[0]) : "v"(w03), "s"(pair(4)));
-        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[1]) : "v"(w03), "s"(pair(6)));
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc[2]) : "v"(w03), "s"(pair(8)));
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[3]) : "v"(w56), "s"(pair(10)));
-        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[4]) : "v"(w56), "s"(pair(12)));
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc[5]) : "v"(w56), "s"(pair(14)));
+        auto spair = [&](int at) __attribute__((always_inline)) {
+            return at < 16 ? u32x2{r.a[at & 15], r.a[(at + 1) & 15]} : u32x2{r.b[(at - 16) & 15], r.b[(at - 15) & 15]};
+        };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(rg[k]) : "v"(w[k]), "s"(spair(8 + 6 * k)));      // first record
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(rg[k]) : "v"(w[k]), "s"(spair(10 + 6 * k)));       // second record
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(bb[k]) : "v"(w[k]), "s"(spair(12 + 6 * k)));                      // blue of both
+        }
     };
     auto flush = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            dacc[2 * q] += (double)acc[q].x;
-            dacc[2 * q + 1] += (double)acc[q].y;
-            acc[q] = f32x2{0.0f, 0.0f};
+        for (int k = 0; k < 4; k++) {
+            dacc[3 * k] += (double)rg[k].x;
+            dacc[3 * k + 1] += (double)rg[k].y;
+            dacc[3 * k + 2] += (double)bb[k].x;
+            dacc[3 * k + 2] += (double)bb[k].y;
+            rg[k] = f32x2{0.0f, 0.0f};
+            bb[k] = f32x2{0.0f, 0.0f};
         }
     };
 
-    // Two scalar register sets (ping-pong, so nothing is copied): the next record is fetched
+    // Two scalar register sets (ping-pong, so nothing is copied): the next block is fetched
     // while the current one is evaluated.
     LsRec ra, rb;
-    const uint32_t last = n_rec - 1u;
+    const uint32_t last = n_blk - 1u;
     ls_rec_load(ra, rp);
-    for (uint32_t e = 0; e < n_rec; e += 2) {
+    for (uint32_t e = 0; e < n_blk; e += 2) {
         ls_rec_wait(ra);
-        ls_rec_load(rb, rp + (size_t)min(e + 1u, last) * LS_REC);
+        ls_rec_load(rb, rp + (size_t)min(e + 1u, last) * (2 * LS_REC));
         eval(ra);
         ls_rec_wait(rb);
-        ls_rec_load(ra, rp + (size_t)min(e + 2u, last) * LS_REC);
-        if (e + 1u < n_rec) eval(rb);
-        if ((e & (uint32_t)(LS_CHUNK - 1)) == (uint32_t)(LS_CHUNK - 2)) flush();      // every LS_CHUNK records
+        ls_rec_load(ra, rp + (size_t)min(e + 2u, last) * (2 * LS_REC));
+        if (e + 1u < n_blk) eval(rb);
+        if ((e & (uint32_t)(LS_CHUNK / 2 - 1)) == (uint32_t)(LS_CHUNK / 2 - 2)) flush();      // every LS_CHUNK records
     }
     ls_rec_wait(ra);       // nothing is in flight when the wave ends
     flush();
