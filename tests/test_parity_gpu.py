@@ -392,6 +392,23 @@ def test_ggx_512_subset_16x16_patches(ibl, orc, kernel_mode):
         _check_cube(orc, got, want, sel=slice(begin, begin + count), tight=GGX_TIGHT, label="ggx 512 level %d" % m)
 
 
+@pytest.mark.parametrize("w", [192, 320])
+def test_ggx_patch_sizes_between_the_powers_of_two(ibl, orc, w, kernel_mode):
+    """Inputs whose patches are not 16 x 16 or whose patch grid is not a power of two (192: 12 x 12
+    texels = 9 groups of 16 records per patch octet; 320: 20 x 20 patches of 16 x 16): bands of output
+    texels of the first and the last level against the oracle, whatever kernel the sizes select."""
+    env, env_d = _env(ibl, orc, w, seed=11)
+    mips = orc.ggx_mip_levels(w, w, 16)
+    for m in (1, mips):
+        ow = w >> m
+        n_out = 6 * ow * ow
+        count = min(n_out, 96)
+        begin = (n_out - count) // 2 + (7 if n_out > count + 7 else 0)
+        got = ibl.ggx_level(env_d, ow, m, mips, out_begin=begin, out_count=count).cpu().numpy()
+        want = orc.ggx_level(env, ow, ow, m, mips, out_begin=begin, out_count=count)
+        _check_cube(orc, got, want, sel=slice(begin, begin + count), tight=GGX_TIGHT, label="ggx %d level %d" % (w, m))
+
+
 _ENV2048 = {}
 
 
