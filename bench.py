@@ -58,10 +58,14 @@ LAMB_SPLIT_FLOP_PER_LANE_RECORD = 38
 GGX_FLOP_PER_LANE_WALKED = 5
 GGX_FLOP_PER_LANE_EVALUATED = 62
 # Matrix form of ggx_oct_pairs (the default for inputs of 64 x 64 and more): the vector pipe keeps the
-# cosine (5) and the weight (12), and cuts the weight into two bf16 pieces (2 conversions, 1 fused
-# multiply-subtract: 4): 16 per record evaluated.  The 25 sums are v_mfma_f32_32x32x16_bf16: 3 partial
+# cosine (5) and the weight (u, t, d as FMAs 6, sqrt + rcp 2, the window's clamped subtraction 1, four
+# multiplies 4: 13), and cuts the weight into two bf16 pieces (2 conversions, 1 fused multiply-subtract:
+# 4): 17 per record evaluated.  Where the window ends above the horizon and the input is 1024 x 1024 or
+# more the weight is u, t, d 6, the clamped subtraction 1, d^2, t d^2 2, an FMA 2, rsq 1, four
+# multiplies 4: 16, with the cut 20.  The 25 sums are v_mfma_f32_32x32x16_bf16: 3 partial
 # products x 32 columns x 2 flop = 192 per lane and record on the matrix pipe (peak 2.5 PFLOP/s dense).
-GGX_MX_FLOP_PER_LANE_EVALUATED = 16
+GGX_MX_FLOP_PER_LANE_EVALUATED = 17
+GGX_MX_RSQ_FLOP_PER_LANE_EVALUATED = 20
 GGX_MX_MATRIX_FLOP_PER_LANE_RECORD = 192
 BF16_MATRIX_PEAK_TFLOPS = 2500.0
 FLOP_PER_GGX_ACCEPTED = 30          # pair by pair
@@ -183,13 +187,18 @@ class Workload:
                            and bool(lv1["my_wave_records"]))
             self.matrix_flop_per_launch = None
             if lv1["my_wave_records"] and self.matrix:
-                self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED + GGX_MX_FLOP_PER_LANE_EVALUATED) \
-                    * lv1["my_wave_records"]
+                # which weight form level 1 takes: the library's rule (ggx_oct_launch)
+                rsq_knob = ibl.get_tuning("ggx_rsq")
+                narrow = ibl.ggx_level_params(1, self.mips, self.env_w, self.env_w)["cutoff"] >= 0.51
+                self.rsq = narrow and (rsq_knob == 2 or (rsq_knob == 1 and self.env_w >= 1024))
+                per_record = GGX_MX_RSQ_FLOP_PER_LANE_EVALUATED if self.rsq else GGX_MX_FLOP_PER_LANE_EVALUATED
+                self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED + per_record) * lv1["my_wave_records"]
                 self.matrix_flop_per_launch = 64.0 * GGX_MX_MATRIX_FLOP_PER_LANE_RECORD * lv1["my_wave_records"]
             elif lv1["my_wave_records"]:
                 self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED * lv1["my_wave_records"]
                                                         + GGX_FLOP_PER_LANE_EVALUATED * lv1["my_wave_evaluated"])
-            self.kernel = "ggx_oct_pairs%s (level 1)" % (", matrix form" if self.matrix else "")
+            self.kernel = "ggx_oct_pairs%s (level 1)" % (
+                (", matrix form, rsq weights" if getattr(self, "rsq", False) else ", matrix form") if self.matrix else "")
             self.desc = ("C%s: GGX prefilter chain of a %dx%d/face environment, %d levels, --input-downscale %d; "
                          "samples = in-patch texel tests (%.3g tested, %.3g accepted)"
                          % (name[1], self.in_w, self.in_w, self.mips, self.down, tested, accepted))

@@ -143,7 +143,11 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
  * factor (16 significant bits; knob "ggx_matrix", 1 by default, 0 keeps them in FP32 on the vector
  * pipe): measured against the FP32 form <= 1e-6 on environments where more than a handful of
  * texels lie under a lobe (99.99 % of the RGBE texels identical), and mean 1.6e-6 / at most 2e-5
- * for a single lit texel in a black environment, where nothing averages the cuts. */
+ * for a single lit texel in a black environment, where nothing averages the cuts.  On inputs of
+ * 1024 x 1024 and more, at the levels whose acceptance window ends above the horizon
+ * (cutoff > 1/2), that form takes sqrt(NoH^2) / denom^2 of cube.cpp:280-281 as one reciprocal
+ * square root (knob "ggx_rsq": 1 this rule, 0 never, 2 at every such level; the two forms agree
+ * to 5e-7). */
 int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
                       uint32_t mip_level, uint32_t mip_levels,
                       uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
@@ -318,7 +322,7 @@ int ibl_set_kernel_mode(int general_only);
 /* Launch-shape knobs of the kernels (slice counts, grid orders; the names are the
  * library's own, the tools under tools/ use them).  They change speed only, except
  * the slice counts, which fix the order of the sums and with it the last bits, and
- * "lamb_split" / "ggx_matrix", which choose between two forms of the arithmetic (see
+ * "lamb_split" / "ggx_matrix" / "ggx_rsq", which choose between two forms of the arithmetic (see
  * ibl_lambertian_dev and ibl_ggx_level_dev). */
 int ibl_set_tuning(const char* name, double value);
 /* The current value of a knob ("general_only" reads back ibl_set_kernel_mode). */

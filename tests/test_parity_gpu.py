@@ -541,6 +541,35 @@ def test_ggx_matrix_form_against_vector_form(ibl, orc):
     assert ibl.get_tuning("ggx_matrix") == 1.0
 
 
+def test_ggx_rsq_weight_form(ibl, orc):
+    """The matrix kernel's second weight form (sqrt(t) / d^2 as t * rsq(t d^4), used where the
+    acceptance window ends above the horizon; by default only for inputs from 1024 x 1024):
+    forced on (ggx_rsq 2) it meets the oracle bar on a whole narrow level of a 256 x 256 input,
+    agrees with the v_sqrt_f32 / v_rcp_f32 form (ggx_rsq 0) to 2e-6, and changes nothing on a
+    level whose window reaches the horizon."""
+    t = ibl.torch
+    env, env_d = _env(ibl, orc, 256, seed=9)
+    mips = 4
+    assert ibl.ggx_level_params(1, mips, 256, 256)["cutoff"] > 0.51
+    assert ibl.ggx_level_params(3, mips, 256, 256)["cutoff"] < 0.5
+    try:
+        ibl.set_tuning("ggx_rsq", 0)
+        plain1 = ibl.ggx_level(env_d, 128, 1, mips)
+        plain3 = ibl.ggx_level(env_d, 32, 3, mips)
+        ibl.set_tuning("ggx_rsq", 2)
+        rsq1 = ibl.ggx_level(env_d, 128, 1, mips)
+        rsq3 = ibl.ggx_level(env_d, 32, 3, mips)
+        assert t.equal(rsq3, plain3)
+        rel = ((rsq1[..., :3].double() - plain1[..., :3].double()).abs() / plain1[..., :3].double()).max().item()
+        assert 0.0 < rel < 2e-6, rel
+        want = orc.ggx_level(env, 128, 128, 1, mips)
+        _check_cube(orc, rsq1.cpu().numpy(), want, tight=GGX_TIGHT, label="ggx 256 level 1/4, rsq weights")
+        ibl.set_tuning("ggx_rsq", 1)
+        assert t.equal(ibl.ggx_level(env_d, 128, 1, mips), plain1)      # below 1024 x 1024 the default is the plain form
+    finally:
+        ibl.set_tuning("ggx_rsq", 1)
+
+
 def test_ggx_rejects_small_and_bad_levels(ibl, orc):
     _, env_d = _env(ibl, orc, 16)
     small = ibl.torch.ones((6, 8, 8, 4), dtype=ibl.torch.float32, device=ibl.device)

@@ -274,21 +274,44 @@ __device__ __forceinline__ float go_weight(float c, float ux, float uy, float uz
     return f;
 }
 
-// Two records at once (matrix form, patches away from the lobe core): the same operations in the
-// same order as go_weight, the multiplies, adds and FMAs as v_pk_*_f32 on the pair.
-typedef float go_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ go_f32x2 go_weight_pair(go_f32x2 c, float thr, float a2p, const GoConst& k) {
-    const go_f32x2 half = { 0.5f, 0.5f }, mhalf = { -0.5f, -0.5f }, one = { 1.0f, 1.0f };
-    const go_f32x2 om = { k.om_a2, k.om_a2 }, a2 = { a2p, a2p };
-    go_f32x2 u = __builtin_elementwise_fma(mhalf, c, half);
-    go_f32x2 t = one - u;
-    go_f32x2 d = __builtin_elementwise_fma(u, om, a2);
-    const go_f32x2 sq = { __builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y) };
-    const go_f32x2 rd = { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y) };
-    const go_f32x2 cw = { sub_clamp01(t.x, thr), sub_clamp01(t.y, thr) };
-    go_f32x2 qd = cw * rd;
-    const go_f32x2 m = { mul_clamp01(c.x, sq.x), mul_clamp01(c.y, sq.y) };
-    return m * (qd * qd);
+// Four records at once (matrix form, patches away from the lobe core): the same operations in the
+// same order as go_weight, the multiplies, adds and FMAs as v_pk_*_f32 on a 4-vector, which the
+// compiler issues as two packed instructions per operation, the halves alternating -- so that no
+// packed instruction reads the result of the one right before it (the compiler puts a wait state
+// between two such, and a wait state costs an issue slot like any instruction).
+// NARROW (cutoff > 1/2, i.e. the acceptance window ends above the horizon): a texel inside the
+// window has a positive cosine, so the horizon clamp of c sqrt(t) has nothing to do, and
+// sqrt(t) / d^2 is taken as t rsq(t d^4): one half-rate instruction per record instead of two
+// (v_sqrt_f32, v_rcp_f32) and no unpacked multiply, for three more packed multiplies per pair.
+// t d^4 cannot be 0 (the smallest normal float is added: d >= alpha^2 > 1e-4, so it changes no
+// value above 1e-30, and at t = 0, where the window's clamp has long made the weight 0, it keeps
+// rsq finite).
+typedef float go_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NARROW>
+__device__ __forceinline__ go_f32x4 go_weight_quad(go_f32x4 c, float thr, float a2p, const GoConst& k) {
+    const go_f32x4 half = { 0.5f, 0.5f, 0.5f, 0.5f }, mhalf = -half;
+    const go_f32x4 om = { k.om_a2, k.om_a2, k.om_a2, k.om_a2 }, a2 = { a2p, a2p, a2p, a2p };
+    go_f32x4 u = __builtin_elementwise_fma(mhalf, c, half);
+    go_f32x4 t = __builtin_elementwise_fma(half, c, half);      // (as 1 - u the compiler issues four unpacked subtractions)
+    go_f32x4 d = __builtin_elementwise_fma(u, om, a2);
+    const go_f32x4 cw = { sub_clamp01(t.x, thr), sub_clamp01(t.y, thr), sub_clamp01(t.z, thr), sub_clamp01(t.w, thr) };
+    if constexpr (NARROW) {
+        const float tn = 1.1754944e-38f;
+        const go_f32x4 tiny = { tn, tn, tn, tn };
+        const go_f32x4 d2 = d * d;
+        const go_f32x4 e = __builtin_elementwise_fma(t * d2, d2, tiny);
+        const go_f32x4 r = { __builtin_amdgcn_rsqf(e.x), __builtin_amdgcn_rsqf(e.y), __builtin_amdgcn_rsqf(e.z),
+                             __builtin_amdgcn_rsqf(e.w) };
+        return c * ((cw * cw) * (t * r));
+    } else {
+        const go_f32x4 sq = { __builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y), __builtin_amdgcn_sqrtf(t.z),
+                              __builtin_amdgcn_sqrtf(t.w) };
+        const go_f32x4 rd = { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z),
+                              __builtin_amdgcn_rcpf(d.w) };
+        go_f32x4 qd = cw * rd;
+        const go_f32x4 m = { mul_clamp01(c.x, sq.x), mul_clamp01(c.y, sq.y), mul_clamp01(c.z, sq.z), mul_clamp01(c.w, sq.w) };
+        return m * (qd * qd);
+    }
 }
 
 template <bool COUNT, bool CORE>
@@ -325,7 +348,7 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
 #ifndef GO_MX_TERMS
 #define GO_MX_TERMS 3                    // 3: hi*hi + hi*mid + mid*hi;  4: + mid*mid
 #endif
-template <bool COUNT, bool EARLY, bool MX = false>
+template <bool COUNT, bool EARLY, bool MX = false, bool NARROW = false>
 __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_WAVES)) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn, const uint32_t* __restrict__ units,
     uint32_t n_po, uint32_t ps2,
@@ -335,6 +358,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
     float* __restrict__ partial, unsigned long long* __restrict__ counts) {
     static_assert(GO_WG == 64, "one wave per workgroup: the grid below is counted in waves");
     static_assert(!(MX && (COUNT || EARLY)), "the matrix form neither counts nor drops records");
+    static_assert(MX || !NARROW, "NARROW selects the weight form of the matrix kernel");
     // the run's running sums: [sum][lane] (matrix form: rows padded, its fold walks down the sums)
     __shared__ float s_run[GO_SUMS][MX ? GO_WG + 1 : GO_WG];
     const uint32_t lane = threadIdx.x & 63;
@@ -604,18 +628,18 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                                         __attribute__((always_inline)) {
                             float f[4];
                             if constexpr (!CORE) {
-#pragma unroll
-                                for (int e = 0; e < 4; e += 2) {
-                                    const go_f32x2 ux = { __uint_as_float(src.v[e]), __uint_as_float(src.v[e + 1]) };
-                                    const go_f32x2 uy = { __uint_as_float(src.v[4 + e]), __uint_as_float(src.v[5 + e]) };
-                                    const go_f32x2 uz = { __uint_as_float(src.v[8 + e]), __uint_as_float(src.v[9 + e]) };
-                                    const go_f32x2 nx = { nt.x, nt.x }, ny = { nt.y, nt.y }, nz = { nt.z, nt.z };
-                                    go_f32x2 c = nx * ux;
-                                    c = __builtin_elementwise_fma(ny, uy, c);
-                                    c = __builtin_elementwise_fma(nz, uz, c);
-                                    const go_f32x2 w = go_weight_pair(c, thr, a2p, kc);
-                                    f[e] = w.x; f[e + 1] = w.y;
-                                }
+                                auto f4 = [&](int o) __attribute__((always_inline)) {
+                                    const go_f32x4 v = { __uint_as_float(src.v[o]), __uint_as_float(src.v[o + 1]),
+                                                         __uint_as_float(src.v[o + 2]), __uint_as_float(src.v[o + 3]) };
+                                    return v;
+                                };
+                                const go_f32x4 nx = { nt.x, nt.x, nt.x, nt.x }, ny = { nt.y, nt.y, nt.y, nt.y },
+                                               nz = { nt.z, nt.z, nt.z, nt.z };
+                                go_f32x4 c = nx * f4(0);
+                                c = __builtin_elementwise_fma(ny, f4(4), c);
+                                c = __builtin_elementwise_fma(nz, f4(8), c);
+                                const go_f32x4 w = go_weight_quad<NARROW>(c, thr, a2p, kc);
+                                f[0] = w.x; f[1] = w.y; f[2] = w.z; f[3] = w.w;
                             } else {
                                 // near the lobe core: record by record (two exact denominators side by side cost
                                 // more registers than 4 waves per SIMD leave)
@@ -930,6 +954,11 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     // with it).  It changes no sum -- a skipped record has weight 0 in every lane -- so the choice
     // may depend on the call's size.
     const bool early_records = early && !matrix && (uint64_t)pl.runs_per_pass * pl.out_units >= 24576u;
+    // The window ends above the horizon (with room for the rounding of t): the weights may take the
+    // v_rsq_f32 form of go_weight_quad.  Measured: 2048 -> 1024 511 -> 495 ms, 2048 -> 512 902 -> 872 ms,
+    // 1024 -> 512 46.8 -> 46.2 ms, but 512 -> 256 5.9 -> 6.4 ms; so from 1024 x 1024 inputs on
+    // (knob ggx_rsq: 0 never, 2 wherever the window allows).
+    const bool narrow = pl.lv.cutoff >= 0.51f && (tuning().ggx_rsq == 2 || (tuning().ggx_rsq == 1 && in_w >= 1024u));
     if (ev0) (void)hipEventRecord(ev0, stream);
     for (uint32_t pass = 0; pass < pl.passes; pass++) {
         const uint32_t run_base = pass * pl.runs_per_pass;
@@ -940,7 +969,7 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
                 pl.lv.cutoff, a2m1, cmin, d_counts ? theta_acc : theta_walk, core_thr, d_runs, d_counts);
         };
         if (d_counts) { if (early_records) go(ggx_oct_pairs<true, true>); else go(ggx_oct_pairs<true, false>); }
-        else if (matrix) go(ggx_oct_pairs<false, false, true>);
+        else if (matrix) { if (narrow) go(ggx_oct_pairs<false, false, true, true>); else go(ggx_oct_pairs<false, false, true, false>); }
         else          { if (early_records) go(ggx_oct_pairs<false, true>); else go(ggx_oct_pairs<false, false>); }
         if (pass + 1 == pl.passes && ev1) (void)hipEventRecord(ev1, stream);
         if (pl.reduce_groups > 1)

@@ -9,7 +9,7 @@ namespace ibl {
 
 // Tuning and diagnostic knobs.  ibl_init reads them from the environment once
 // (IBL_NO_OCTETS, IBL_LAMB_P, IBL_LAMB_OCT_SLICES, IBL_LAMB_OCT_RUN, IBL_LAMB_OCT_AFFINE,
-// IBL_LAMB_SPLIT, IBL_GGX_WAVES, IBL_GGX_XCD_SLICES, IBL_GGX_CORE, IBL_GGX_MATRIX); no entry point looks at the
+// IBL_LAMB_SPLIT, IBL_GGX_WAVES, IBL_GGX_XCD_SLICES, IBL_GGX_CORE, IBL_GGX_MATRIX, IBL_GGX_RSQ); no entry point looks at the
 // environment afterwards.  ibl_set_tuning / ibl_get_tuning reach all of them by name.
 struct Tuning {
     bool no_octets = false;        // general kernels only
@@ -24,6 +24,7 @@ struct Tuning {
     int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
     int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
+    int ggx_rsq = 1;               // ... its weights at narrow lobes through one v_rsq_f32: 1 for inputs from 1024 x 1024, 2 always, 0 never
     float lamb_split_limit = 16.0f; // ... blocks whose texels cancel by more than this factor are redone with exact weights
 };
 Tuning& tuning();
