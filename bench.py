@@ -197,8 +197,7 @@ class Workload:
             elif lv1["my_wave_records"]:
                 self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED * lv1["my_wave_records"]
                                                         + GGX_FLOP_PER_LANE_EVALUATED * lv1["my_wave_evaluated"])
-            self.kernel = "ggx_oct_pairs%s (level 1)" % (
-                (", matrix form, rsq weights" if getattr(self, "rsq", False) else ", matrix form") if self.matrix else "")
+            self.kernel = "ggx_oct_pairs%s (level 1)" % (", matrix form" if self.matrix else "")
             self.desc = ("C%s: GGX prefilter chain of a %dx%d/face environment, %d levels, --input-downscale %d; "
                          "samples = in-patch texel tests (%.3g tested, %.3g accepted)"
                          % (name[1], self.in_w, self.in_w, self.mips, self.down, tested, accepted))
@@ -511,6 +510,8 @@ def main():
             line["roofline"]["matrix_bf16_tflops"] = round(mtf, 1)
             line["roofline"]["frac_of_bf16_matrix_peak"] = round(mtf / BF16_MATRIX_PEAK_TFLOPS, 4)
             line["roofline"]["both_pipes_frac"] = round(achieved / FP32_VECTOR_PEAK_TFLOPS + mtf / BF16_MATRIX_PEAK_TFLOPS, 4)
+        if getattr(wl, "rsq", False):
+            line["roofline"]["weight_form"] = "one v_rsq_f32 per record (window ends above the horizon)"
         if getattr(wl, "exact_octets", None) is not None:
             # output octets whose even and odd halves cancel too far and were redone with exact weights
             line["roofline"]["exact_weight_octets"] = wl.exact_octets

@@ -40,7 +40,8 @@ def main():
                 out = ibl.ggx_level(env, ow, m, mips)
                 best = min(best, ibl.last_kernel_ms())
             totals[name] += best
-            line = "level %d out %4d  %-16s %9.3f ms" % (m, ow, name, best)
+            line = "level %d out %4d  %-16s %9.3f ms  bits %016x" % (
+                m, ow, name, best, int(out.view(torch.int32).to(torch.int64).sum().item()) & 0xffffffffffffffff)
             if ref is None:
                 ref = out.clone()
             else:

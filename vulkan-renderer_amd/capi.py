@@ -14,7 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libibl_hip.so")
+# (IBL_HIP_LIB: another build of the same library, e.g. a kernel variant under tools/variants/)
+LIB_PATH = os.environ.get("IBL_HIP_LIB") or os.path.join(_HERE, "libibl_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "ibl_hip.h")
 
 SHARD_LAMBERTIAN = 0

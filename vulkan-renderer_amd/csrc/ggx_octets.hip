@@ -660,6 +660,9 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                             }
                             h0 = go_pack_bf16(f[0], f[1]);
                             h1 = go_pack_bf16(f[2], f[3]);
+                            // (v_dot2c_f32_bf16 with (-1, 0) / (0, -1) would subtract a half of h0 from f in one
+                            // instruction, but it does not keep the FP32 addend's low bits: the lower pieces came
+                            // out wrong by 1e-2)
                             m0 = go_pack_bf16(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u));
                             m1 = go_pack_bf16(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
                         };
