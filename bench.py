@@ -59,8 +59,8 @@ GGX_FLOP_PER_LANE_WALKED = 5
 GGX_FLOP_PER_LANE_EVALUATED = 62
 # Matrix form of ggx_oct_pairs (the default for inputs of 64 x 64 and more): the vector pipe keeps the
 # cosine (5) and the weight (u, t, d as FMAs 6, sqrt + rcp 2, the window's clamped subtraction 1, four
-# multiplies 4: 13), and cuts the weight into two bf16 pieces (2 conversions, 1 fused multiply-subtract:
-# 4): 17 per record evaluated.  Where the window ends above the horizon and the input is 1024 x 1024 or
+# multiplies 4: 13), and cuts the weight into two bf16 pieces (2 conversions, 1 v_dot2c_f32_bf16 counted as a
+# fused multiply-add: 4): 17 per record evaluated.  Where the window ends above the horizon and the input is 1024 x 1024 or
 # more the weight is u, t, d 6, the clamped subtraction 1, d^2, t d^2 2, an FMA 2, rsq 1, four
 # multiplies 4: 16, with the cut 20.  The 25 sums are v_mfma_f32_32x32x16_bf16: 3 partial
 # products x 32 columns x 2 flop = 192 per lane and record on the matrix pipe (peak 2.5 PFLOP/s dense).

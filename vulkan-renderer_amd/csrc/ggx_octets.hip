@@ -348,6 +348,9 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
 #ifndef GO_MX_TERMS
 #define GO_MX_TERMS 3                    // 3: hi*hi + hi*mid + mid*hi;  4: + mid*mid
 #endif
+#ifndef GO_CUT_DOT2
+#define GO_CUT_DOT2 1                    // lower pieces of the weights through v_dot2c_f32_bf16 (0: shift, mask, FMA)
+#endif
 template <bool COUNT, bool EARLY, bool MX = false, bool NARROW = false>
 __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_WAVES)) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn, const uint32_t* __restrict__ units,
@@ -454,6 +457,9 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
     axx = uniform(axx); axy = uniform(axy); axz = uniform(axz);
     wave_thr = uniform(wave_thr); core_cos = uniform(core_cos);
 
+    // bf16 pairs (-1, -0) and (-0, -1).  (With +0 the first is the bit pattern of an inline constant,
+    // which this instruction does not read as a bf16 pair: results were off by 1e-2.)
+    constexpr uint32_t cut_lo = 0x8000bf80u, cut_hi = 0xbf808000u;
     float acc[8][3], accw = 0.0f;     // FP32 chunk sums, indexed by input member
 #pragma unroll
     for (int m = 0; m < 8; m++)
@@ -661,10 +667,20 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                             h0 = go_pack_bf16(f[0], f[1]);
                             h1 = go_pack_bf16(f[2], f[3]);
                             // (v_dot2c_f32_bf16 with (-1, 0) / (0, -1) would subtract a half of h0 from f in one
-                            // instruction, but it does not keep the FP32 addend's low bits: the lower pieces came
-                            // out wrong by 1e-2)
-                            m0 = go_pack_bf16(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u));
-                            m1 = go_pack_bf16(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
+                            // instruction and ran 2 % faster, but the lower pieces it gave were not the exact
+                            // differences: levels came out 1e-2 off)
+                            if constexpr (GO_CUT_DOT2 && !CORE) {
+                                // rounded weight minus its upper piece in one instruction, h . (-1, -0) + f
+                                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                                auto sub = [](uint32_t h, uint32_t k, float x) {
+                                    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, h), __builtin_bit_cast(bf16x2, k), x, false);
+                                };
+                                m0 = go_pack_bf16(sub(h0, cut_lo, f[0]), sub(h0, cut_hi, f[1]));
+                                m1 = go_pack_bf16(sub(h1, cut_lo, f[2]), sub(h1, cut_hi, f[3]));
+                            } else {
+                                m0 = go_pack_bf16(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u));
+                                m1 = go_pack_bf16(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
+                            }
                         };
                         go_dir_load(da, dp);
                         for (uint32_t g = 0; g < ps2; g += GO_MX_GROUP) {
