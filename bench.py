@@ -106,6 +106,9 @@ class Workload:
         # several ranks on one GPU over gloo (rehearsal only): collectives go through host tensors,
         # see sharding.gather_cube
         self.via_host = world > 1 and dist.get_backend() == "gloo"
+        # IBL_BENCH_EXCHANGE_ALWAYS=1: a single rank also packs, all-gathers (over RCCL) and scatters every cube,
+        # which puts the fixed cost of the exchange step inside the timed step of a one-GPU run
+        self.always = os.environ.get("IBL_BENCH_EXCHANGE_ALWAYS") == "1"
         self.sharding, self.capi = sharding, capi
         t = ibl.torch
         self.kernel_ms = []
@@ -247,7 +250,7 @@ class Workload:
     def _gather(self, kind, in_w, cube, mip=1, mips=1):
         """The exchange step: pack this rank's shard, one all-gather, scatter every shard."""
         self.sharding.gather_cube(self.dist, self.ibl, kind, in_w, cube, mip, mips, self.rank, self.world,
-                                  via_host=self.via_host)
+                                  via_host=self.via_host, always=self.always)
 
     def step(self):
         ibl, d = self.ibl, self.dist
@@ -451,8 +454,10 @@ def main():
     if os.environ.get("IBL_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    grouped = world > 1 or os.environ.get("IBL_BENCH_EXCHANGE_ALWAYS") == "1"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend, rank=rank, world_size=world)
     ibl = vra.Ibl(local_rank)
     ibl.set_timing(True)
@@ -484,7 +489,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl.desc,
-                       "parallelism": "output shards over %d GPU(s), one all-gather per cube" % world,
+                       "parallelism": "output shards over %d GPU(s), one all-gather per cube%s" % (
+                           world, " (run for the single rank too)" if wl.always else ""),
                        "seed": args.seed},
             "roofline": {
                 "bound": "fp32_valu",
@@ -562,7 +568,7 @@ def main():
                 line.update(extra)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -152,3 +152,30 @@ def test_multi_gpu_bake_writes_the_same_pixels(tmp_path):
     assert names == sorted(os.listdir(b)) == ["sky.ggx1.png", "sky.ggx2.png", "sky.ggx3.png", "sky.lambertian.png", "sky.png"]
     for name in names:
         np.testing.assert_array_equal(read_png(str(a / name)), read_png(str(b / name)), err_msg=name)
+
+
+def test_one_rank_bake_over_rccl_writes_the_same_pixels(tmp_path):
+    """The exchange step with the backend the real path uses: vulkan_renderer_amd.bake as ONE rank over
+    RCCL (a one-GPU box cannot hold more: RCCL refuses two ranks per device), made to pack, all-gather
+    and scatter every cube all the same (IBL_BAKE_EXCHANGE_ALWAYS), against bin/cube."""
+    import shutil
+    import sys
+    strip = vra.synth.hdr_environment(64, seed=22)
+    a, b = tmp_path / "tool", tmp_path / "rccl"
+    a.mkdir()
+    b.mkdir()
+    write_png(str(a / "sky.png"), strip)
+    shutil.copy(str(a / "sky.png"), str(b / "sky.png"))
+    flags = ["--lambertian", "--ggx", "--cubemap-size", "16"]
+    r = subprocess.run([CUBE] + flags + [str(a / "sky.png")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, IBL_BAKE_EXCHANGE_ALWAYS="1", PYTHONPATH=ROOT)
+    env.pop("IBL_BAKE_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", "-m", "vulkan_renderer_amd.bake"]
+                       + flags + [str(b / "sky.png")], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    names = sorted(os.listdir(a))
+    assert names == sorted(os.listdir(b)) == ["sky.ggx1.png", "sky.ggx2.png", "sky.lambertian.png", "sky.png"]
+    for name in names:
+        np.testing.assert_array_equal(read_png(str(a / name)), read_png(str(b / name)), err_msg=name)

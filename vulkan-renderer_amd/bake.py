@@ -43,15 +43,21 @@ def main(argv=None):
     backend = os.environ.get("IBL_BAKE_BACKEND", "nccl")
     if os.environ.get("IBL_BAKE_SAME_DEVICE") == "1":
         local_rank = 0
+    # IBL_BAKE_EXCHANGE_ALWAYS=1: a single rank also joins a process group and runs pack, all-gather and
+    # scatter (one rank over RCCL is what a one-GPU box can run of the real exchange step)
+    always = os.environ.get("IBL_BAKE_EXCHANGE_ALWAYS") == "1"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    grouped = world > 1 or always
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend, rank=rank, world_size=world)
     ibl = capi.Ibl(local_rank)
 
     def assemble(kind, in_w, cube, mip=1, mips=1):
         # over gloo on one shared GPU (rehearsal) the shards travel through host tensors: see sharding.gather_cube
-        return sharding.gather_cube(dist, ibl, kind, in_w, cube, mip, mips, rank, world, via_host=backend == "gloo")
+        return sharding.gather_cube(dist, ibl, kind, in_w, cube, mip, mips, rank, world, via_host=backend == "gloo",
+                                    always=always)
 
     strip = pngio.read_rgba8(args.file)
     h6, w = strip.shape[0], strip.shape[1]
@@ -80,7 +86,7 @@ def main(argv=None):
             out = torch.zeros((6, size, size, 4), dtype=torch.float32, device=ibl.device)
             ibl.ggx_level_shard(env, size, m, mips, rank, world, out=out)
             write(".ggx%d.png" % m, assemble(capi.SHARD_GGX, int(env.shape[2]), out, m, mips), size)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -40,11 +40,11 @@ def all_gather_ranges(dist, out_flat, n_units, rank, world_size, group=None, via
     return out_flat
 
 
-def all_gather_packed(dist, packed, world_size, group=None, via_host=False):
+def all_gather_packed(dist, packed, world_size, group=None, via_host=False, always=False):
     """One all-gather of equal-size packed shards: (slots, C) per rank -> (world_size * slots, C),
-    shard r at rows [r * slots, (r + 1) * slots).  via_host: see gather_cube."""
+    shard r at rows [r * slots, (r + 1) * slots).  via_host, always: see gather_cube."""
     import torch
-    if world_size == 1:
+    if world_size == 1 and not always:
         return packed
     send = packed.contiguous().cpu() if via_host else packed.contiguous()
     recv = torch.empty((world_size * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
@@ -52,16 +52,17 @@ def all_gather_packed(dist, packed, world_size, group=None, via_host=False):
     return recv.to(packed.device) if via_host else recv
 
 
-def gather_cube(dist, ibl, kind, in_w, cube, mip, mips, rank, world_size, group=None, via_host=False):
+def gather_cube(dist, ibl, kind, in_w, cube, mip, mips, rank, world_size, group=None, via_host=False, always=False):
     """The exchange step of a sharded Lambertian / GGX cube on GPUs: pack this rank's shard of
     `cube`, all-gather, scatter every shard into `cube`.  via_host moves the packed shards
     through host tensors: for rehearsing several ranks on ONE GPU over gloo, whose staging of
     device tensors can hang when ranks share a device (the real path is RCCL on device
-    tensors, one GPU per rank)."""
-    if world_size == 1:
+    tensors, one GPU per rank).  always: run the three steps for a single rank too (the way to
+    put the RCCL collective itself under test on a one-GPU box)."""
+    if world_size == 1 and not always:
         return cube
     packed = ibl.shard_pack(kind, in_w, cube, mip, mips, rank, world_size)
-    every = all_gather_packed(dist, packed, world_size, group=group, via_host=via_host)
+    every = all_gather_packed(dist, packed, world_size, group=group, via_host=via_host, always=always)
     return ibl.shard_unpack(kind, in_w, every, cube, mip, mips, world_size)
 
 
