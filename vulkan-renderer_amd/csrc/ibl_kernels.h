@@ -14,7 +14,7 @@ namespace ibl {
 struct Tuning {
     bool no_octets = false;        // general kernels only
     int lamb_p = 0;                // general Lambertian kernel: output texels per thread (0: automatic)
-    uint32_t lamb_oct_slices = 0;  // octet Lambertian kernels: maximum slice count (0: 341)
+    uint32_t lamb_oct_slices = 0;  // octet Lambertian kernels: maximum slice count (0: 341, and 430 from 1024 x 1024 faces on)
     int lamb_oct_run = -1;         // octet Lambertian kernel: 1 / 0 force / forbid the run form (-1: automatic)
     int lamb_oct_affine = -1;      // octet Lambertian kernel: 1 / 0 force / forbid dealing slots to the XCDs (-1: automatic)
     double ggx_waves = 0.0;        // octet GGX kernel: waves per level to aim for (0: automatic)

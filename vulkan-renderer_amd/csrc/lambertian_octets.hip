@@ -438,14 +438,16 @@ LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks) {
     pl.n_oct_in = 3 * (in_w / 2) * (in_w / 2);
     // Slice length depends on the input size only (range/shard independence).
     uint32_t tiles = (pl.n_oct_in + OCT_TILE - 1) / OCT_TILE;
-    // At most 341 slices (333 for a 1024 x 1024 face).  The count fixes the order of the sums, so it
-    // may depend on the input size only; it is chosen for the 1024 -> 128 cube on 1, 2, 4 and 8 GPUs
-    // at once: 48 / N output blocks x 333 slices is 7.8, 3.9, 1.95 and 0.98 times the 2048 workgroups
-    // a GPU holds (8 per CU), so a shard never leaves a CU with one workgroup more than its
-    // neighbours for a whole slice (an eighth of the cube: 0.61 ms with 333 slices, 0.67 with 300,
-    // 0.96 with 384; the whole cube on one GPU 4.5-4.6 ms with any of them), and the slice sums stay
-    // below twice the bytes the kernel has to move anyway.
-    uint32_t max_slices = tuning().lamb_oct_slices ? tuning().lamb_oct_slices : 341;
+    // At most 341 slices, 430 from 1024 x 1024 faces on (424 for a 1024 x 1024 face).  The count fixes the
+    // order of the sums, so it may depend on the input size only; it is chosen for the 1024 -> 128 cube
+    // on 1, 2, 4 and 8 GPUs at once.  An eighth of that cube is 6 output blocks: with 333 slices its
+    // 1998 workgroups fill the 2048 a GPU holds (8 per CU) just once, and that single round takes
+    // 0.65 ms where an eighth of the whole cube's time is 0.48; with 424 slices (2544 workgroups) it
+    // takes 0.55 ms, with 512 or 683 no less, while the whole cube on one GPU stays at 3.8 ms
+    // (tools/lamb_slices_sweep.py; starting the waves of a SIMD a hundred cycles apart changes nothing).
+    // The slice sums grow with the count: 250 MB written for 153 MB the kernel has to move anyway.
+    // Smaller inputs keep 341, and with it the sizes the static entry point's 64 MiB array holds.
+    uint32_t max_slices = tuning().lamb_oct_slices ? tuning().lamb_oct_slices : (tiles >= 12288u ? 430u : 341u);
     uint32_t tiles_per_slice = (tiles + max_slices - 1) / max_slices;
     if (tiles_per_slice < 2) tiles_per_slice = 2;
     pl.slice_len = tiles_per_slice * OCT_TILE;
