@@ -319,16 +319,26 @@ __global__ __launch_bounds__(LS_THREADS, LS_MIN_WAVES) void ls_pairs(
     }
 }
 
-// The run sums from the slice sums: one thread per (output octet, sum, run).
+// The run sums from the slice sums: one thread per (four output octets, sum, run); the slices of a
+// run are added in order (all eight loads are issued before the first addition: a slice missing at
+// the end of the last run counts as +0).
 __global__ __launch_bounds__(256) void ls_reduce(const float* __restrict__ partial, uint32_t n_slices,
                                                   uint32_t oct_local, double* __restrict__ reduced) {
-    const uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;      // oct_local is a multiple of 256
     const uint32_t q = blockIdx.y, g = blockIdx.z;
     if (lo >= oct_local) return;
-    const uint32_t s0 = g * LS_RUN, s1 = min(n_slices, s0 + LS_RUN);
-    double v = 0.0;
-    for (uint32_t sl = s0; sl < s1; sl++) v += (double)partial[((size_t)sl * LS_SUMS + q) * oct_local + lo];
-    reduced[((size_t)g * LS_SUMS + q) * oct_local + lo] = v;
+    const uint32_t s0 = g * LS_RUN;
+    float4 v[LS_RUN];
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)LS_RUN; k++)
+        v[k] = s0 + k < n_slices ? *(const float4*)(partial + ((size_t)(s0 + k) * LS_SUMS + q) * oct_local + lo)
+                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)LS_RUN; k++) { a += (double)v[k].x; b += (double)v[k].y; c += (double)v[k].z; d += (double)v[k].w; }
+    double* out = reduced + ((size_t)g * LS_SUMS + q) * oct_local + lo;
+    *(double2*)out = make_double2(a, b);
+    *(double2*)(out + 2) = make_double2(c, d);
 }
 
 // One thread per output octet: the runs in order, the inverse transform, the odd half, the scale;
@@ -437,7 +447,7 @@ hipError_t lambertian_split_launch(const LambertianOctPlan& pl, const float* d_e
         ls_pairs<false><<<grid, LS_THREADS, 0, stream>>>((const float4*)d_rec, pl.n_oct_in, pl.slice_len, pl.n_slices, out_size,
             d_block_list, oct_begin, oct_end, pl.out_blocks, affine, out_begin, out_count, d_slices, d_counts);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    ls_reduce<<<dim3((oct_local + 255) / 256, LS_SUMS, pl.n_runs), 256, 0, stream>>>(d_slices, pl.n_slices, oct_local, d_runs);
+    ls_reduce<<<dim3((oct_local / 4 + 255) / 256, LS_SUMS, pl.n_runs), 256, 0, stream>>>(d_slices, pl.n_slices, oct_local, d_runs);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);      // cube.cpp:126
     ls_final<<<(oct_local + 255) / 256, 256, 0, stream>>>(d_runs, pl.n_runs, d_moment, out_size, d_block_list, oct_begin, oct_end,
                                                          pl.out_blocks, out_begin, out_count, scale,
