@@ -101,7 +101,7 @@ def _worker(rank, world, port, n_units_list, ret):
         own = idx[rank][idx[rank] != 0xffffffff].astype(np.int64)
         mine[own] = want[own]
         packed = sharding.pack_by_indices(mine, idx[rank])
-        every = sharding.all_gather_packed(dist, packed, world)
+        every = sharding.all_gather_packed(dist, packed, world, always=True)      # (always: a lone rank gathers too)
         assert every.shape[0] == world * len(idx[rank])
         full = sharding.unpack_by_indices(every, np.concatenate(idx), torch.full_like(want, -1.0))
         ok = ok and bool(torch.equal(full, want))
@@ -123,4 +123,19 @@ def test_two_rank_gloo_bake_equals_single_rank():
     for p in procs:
         p.join(240)
         assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1
+
+
+@pytest.mark.timeout(300)
+def test_one_rank_runs_the_exchange_when_asked():
+    """always=True: a single rank packs, all-gathers (a group of one) and scatters, which is how a
+    one-GPU box runs the RCCL exchange; without it a single rank returns its buffers untouched."""
+    packed = torch.arange(12.0).reshape(3, 4)
+    assert sharding.all_gather_packed(None, packed, 1) is packed
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), [5], ret))
+    p.start()
+    p.join(240)
+    assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
