@@ -30,6 +30,7 @@ def main():
     half = w // 2
     begin = 6 * half * half // 2 + half * 77 + 1000
     want = oracle.ggx_level(env, half, half, 1, mips, out_begin=begin, out_count=8).reshape(-1, 4)[begin:begin + 8, :3]
+    want_px = want
     for name, matrix, rsq, core in (("matrix rsq", 1, 2, 2), ("matrix sqrt+rcp", 1, 0, 2), ("vector", 0, 0, 2),
                                     ("matrix rsq, core 4", 1, 2, 4), ("matrix rsq, core 8", 1, 2, 8),
                                     ("matrix rsq, core 16", 1, 2, 16), ("vector, core 8", 0, 0, 8)):
@@ -41,6 +42,18 @@ def main():
         err = (got.astype(np.float64) - want) / want
         ibl.set_timing(True)
         print("%-28s runs %s  rel err mean %+.3e  max |.| %.3e" % (name, runs, err.mean(), np.abs(err).max()), flush=True)
+    # ... and for several run counts (the fewer the runs, the longer a wave's FP32 running sums)
+    ibl.set_tuning("ggx_matrix", 1)
+    ibl.set_tuning("ggx_rsq", 1)
+    ibl.set_tuning("ggx_core", 2)
+    units = (3 * (half // 2) ** 2 + 63) // 64
+    for want in (1, 3, 8, 24, 96):
+        ibl.set_tuning("ggx_waves", float(want * units))
+        plan = vra.capi.ggx_level_plan(w, half, 1, mips)
+        got = ibl.ggx_level(env_d, half, 1, mips, out_begin=begin, out_count=8).cpu().numpy().reshape(-1, 4)[begin:begin + 8, :3]
+        err = (got.astype(np.float64) - want_px) / want_px
+        print("asked for %3d runs: plan %s  rel err mean %+.3e  max |.| %.3e" % (want, plan, err.mean(), np.abs(err).max()), flush=True)
+    ibl.set_tuning("ggx_waves", 0)
 
 
 if __name__ == "__main__":
