@@ -570,6 +570,37 @@ def test_ggx_rsq_weight_form(ibl, orc):
         ibl.set_tuning("ggx_rsq", 1)
 
 
+@pytest.mark.parametrize("mib", [64, 24])
+def test_ggx_levels_that_add_their_launches_into_one_set_of_sums(ibl, orc, mib):
+    """The plan of levels whose run sums do not fit eight runs at a time (4096 -> 2048 and larger): up
+    to 32 runs, launched as many at a time as fit, every launch added into ONE set of FP64 sums.
+    The knob ggx_sums_mib shrinks the memory a level may take so that the 512 -> 256 level takes that
+    plan (64 MiB: 4 launches of 8 runs; 24 MiB: 11 launches of 3): within 2e-6 of the ordinary plan,
+    shards and narrow ranges equal to the whole level bit for bit, a range against the oracle."""
+    t = ibl.torch
+    env, env_d = _env(ibl, orc, 512, seed=5)
+    usual = ibl.ggx_level(env_d, 256, 1, 5)
+    try:
+        ibl.set_tuning("ggx_sums_mib", mib)
+        plan = vra.capi.ggx_level_plan(512, 256, 1, 5)
+        assert plan["passes"] == {64: 4, 24: 11}[mib] and plan["runs"] in (32, 33)
+        whole = ibl.ggx_level(env_d, 256, 1, 5)
+        rel = ((whole[..., :3].double() - usual[..., :3].double()).abs() / usual[..., :3].double()).max().item()
+        assert 0.0 < rel < 2e-6, rel
+        acc = t.zeros_like(whole)
+        for sh in range(3):
+            acc += ibl.ggx_level_shard(env_d, 256, 1, 5, sh, 3)
+        assert t.equal(acc, whole)
+        begin, count = 6 * 256 * 256 // 2 + 256 * 31 + 77, 192
+        part = ibl.ggx_level(env_d, 256, 1, 5, out_begin=begin, out_count=count)
+        assert t.equal(part.reshape(-1, 4)[begin:begin + count], whole.reshape(-1, 4)[begin:begin + count])
+        want = orc.ggx_level(env, 256, 256, 1, 5, out_begin=begin, out_count=count)
+        _check_cube(orc, part.cpu().numpy(), want, sel=slice(begin, begin + count), tight=GGX_TIGHT,
+                    label="ggx 512 level 1/5, %d MiB of sums" % mib)
+    finally:
+        ibl.set_tuning("ggx_sums_mib", 0)
+
+
 def test_ggx_rejects_small_and_bad_levels(ibl, orc):
     _, env_d = _env(ibl, orc, 16)
     small = ibl.torch.ones((6, 8, 8, 4), dtype=ibl.torch.float32, device=ibl.device)

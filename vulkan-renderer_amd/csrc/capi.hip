@@ -313,6 +313,7 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "ggx_early")) g_tuning.ggx_early = (int)value;
     else if (!strcmp(name, "ggx_matrix")) g_tuning.ggx_matrix = (int)value;
     else if (!strcmp(name, "ggx_rsq")) g_tuning.ggx_rsq = (int)value;
+    else if (!strcmp(name, "ggx_sums_mib")) g_tuning.ggx_sums_mib = value;
     else if (!strcmp(name, "bake_rehearse_shards")) g_tuning.bake_rehearse_shards = (int)value;
     else return fail(IBL_EINVAL, "set_tuning: unknown knob %s", name);
     return IBL_OK;
@@ -333,6 +334,7 @@ int ibl_get_tuning(const char* name, double* value) {
     else if (!strcmp(name, "ggx_early")) *value = g_tuning.ggx_early;
     else if (!strcmp(name, "ggx_matrix")) *value = g_tuning.ggx_matrix;
     else if (!strcmp(name, "ggx_rsq")) *value = g_tuning.ggx_rsq;
+    else if (!strcmp(name, "ggx_sums_mib")) *value = g_tuning.ggx_sums_mib;
     else if (!strcmp(name, "bake_rehearse_shards")) *value = g_tuning.bake_rehearse_shards;
     else if (!strcmp(name, "general_only")) *value = g_tuning.no_octets ? 1.0 : 0.0;
     else return fail(IBL_EINVAL, "get_tuning: unknown knob %s", name);

@@ -762,10 +762,11 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
 // consecutive runs, in order, into one more set of partial sums.  One thread per
 // (output octet, member, group).
 // (partial holds the n_runs runs of one launch; its groups are group_base, group_base + 1, ...)
+// add_to: the group's sums so far are the starting value (a level whose launches all add into one group).
 __global__ __launch_bounds__(256) void ggx_oct_reduce(const float* __restrict__ partial, uint32_t n_runs,
                                                        uint32_t per_group, uint32_t group_base, uint32_t n_oct,
                                                        const uint32_t* __restrict__ units, uint32_t oct_count,
-                                                       double* __restrict__ reduced) {
+                                                       uint32_t add_to, double* __restrict__ reduced) {
     const uint32_t lo = blockIdx.x * GO_THREADS + threadIdx.x;
     if (lo >= oct_count) return;
     const uint32_t gidx = go_global(lo, units);
@@ -775,6 +776,8 @@ __global__ __launch_bounds__(256) void ggx_oct_reduce(const float* __restrict__ 
     // m < 8: the member's RGB sums; m == 8: the octet's weight sum
     const uint32_t j0 = m < 8 ? m * 3 : 24, nj = m < 8 ? 3 : 1;
     double v[3] = {0.0, 0.0, 0.0};
+    if (add_to)
+        for (uint32_t k = 0; k < nj; k++) v[k] = reduced[((size_t)(group_base + g) * GO_SUMS + (j0 + k)) * oct_count + lo];
     for (uint32_t sl = s0; sl < s1; sl++) {
         for (uint32_t k = 0; k < nj; k++) v[k] += (double)partial[((size_t)sl * GO_SUMS + (j0 + k)) * oct_count + lo];
     }
@@ -820,6 +823,7 @@ uint32_t ggx_oct_tile_edge(uint32_t out_w) { return go_tile_edge(out_w / 2); }
 
 GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t n_units) {
     GgxOctPlan pl;
+    pl.accumulate = false;
     pl.lv = ggx_level_params(mip, mips, in_w, in_w);
     const uint32_t ps = pl.lv.patch, pw = in_w / ps;
     pl.n_po = 3 * (pw / 2) * (pw / 2);
@@ -871,9 +875,9 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
         // 3.0 GB; the same bits as one launch would give).  A group never spans two launches, and a
         // launch has a multiple of 8 runs, so that the 8 XCDs can own equal shares of them (see
         // ggx_oct_pairs).  Levels too large even for 8 runs at a time (8192 -> 4096: 1.3 GB per run)
-        // take what fits in one launch.
+        // launch what fits and add every launch into one set of FP64 sums (below).
         const double elems = (double)units_level * GO_UNIT * GO_SUMS;
-        const double budget = (double)(4ull << 30);
+        const double budget = tuning().ggx_sums_mib > 0.0 ? tuning().ggx_sums_mib * 1048576.0 : (double)(4ull << 30);
         auto groups_of = [](uint32_t n) { uint32_t g = n > 64 ? (n + 31) / 32 : 1; return g > 64 ? 64u : g; };
         auto single_fits = [&](uint32_t n) {
             const uint32_t g = groups_of(n);
@@ -896,11 +900,20 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
                     pl.per_group = per_group;
                 }
             }
-            if (pl.passes == 0) {               // not even 8 runs at a time: one launch of what fits
-                uint32_t n = runs;
-                while (n > 1 && !single_fits(n)) n--;
-                pl.passes = 1;
-                pl.runs_per_pass = n >= 16 ? n / 8 * 8 : n;
+            if (pl.passes == 0) {
+                // Not even 8 runs at a time (8192 -> 4096: 1.3 GB per run).  The few runs that fit one launch
+                // would each carry thousands of FP32 chunks in their running sums, and small chunks get lost
+                // in a large running sum (4096 -> 2048 forced to 1 / 3 / 8 runs: 1.8e-5 / 5e-6 / 1.2e-6 against
+                // the CPU statement).  So: up to 32 runs, launched as many at a time as fit beside ONE set of
+                // FP64 sums, which every launch adds its runs into.
+                uint32_t total = runs < 32u ? runs : 32u;
+                uint32_t r = total;
+                while (r > 1 && elems * ((double)r * sizeof(float) + sizeof(double)) > budget) r--;
+                if (r >= 8) r = r / 8 * 8;
+                pl.accumulate = true;
+                pl.runs_per_pass = r;
+                pl.passes = (total + r - 1) / r;
+                pl.per_group = r;
             }
         }
         pl.n_runs = pl.runs_per_pass * pl.passes;
@@ -908,14 +921,16 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     pl.out_units = n_units;
     const uint32_t oct_count = pl.out_units * GO_UNIT;
     // many runs are summed in two stages (fixed grouping, so still one summation order)
-    if (pl.passes > 1) {
+    if (pl.accumulate) {
+        pl.reduce_groups = 1;
+    } else if (pl.passes > 1) {
         pl.reduce_groups = pl.n_runs / pl.per_group;
     } else {
         pl.reduce_groups = pl.n_runs > 64 ? (pl.n_runs + 31) / 32 : 1;
         if (pl.reduce_groups > 64) pl.reduce_groups = 64;
         pl.per_group = (pl.n_runs + pl.reduce_groups - 1) / pl.reduce_groups;
     }
-    const uint32_t stage2 = pl.reduce_groups > 1 ? pl.reduce_groups : 0;
+    const uint32_t stage2 = pl.accumulate ? 1 : (pl.reduce_groups > 1 ? pl.reduce_groups : 0);
     pl.partial_bytes = (size_t)GO_SUMS * oct_count * (pl.runs_per_pass * sizeof(float) + stage2 * sizeof(double));
     // (the counting variant walks the vector form's records: room for the larger of the two)
     pl.rec_bytes = (size_t)pl.n_po * ps * ps * (pl.matrix ? (size_t)GO_MX_REC_BYTES : GO_REC * sizeof(float4));
@@ -959,7 +974,8 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const uint32_t oct_count = pl.out_units * GO_UNIT;
     // workspace: the groups' sums (double) first, then the sums of one launch's runs (float)
     double* d_groups = d_partial;
-    float* d_runs = (float*)(d_partial + (size_t)(pl.reduce_groups > 1 ? pl.reduce_groups : 0) * GO_SUMS * oct_count);
+    const bool two_stage = pl.accumulate || pl.reduce_groups > 1;
+    float* d_runs = (float*)(d_partial + (size_t)(two_stage ? pl.reduce_groups : 0) * GO_SUMS * oct_count);
     const bool early = cmin == 0.0f && tuning().ggx_early != 0;      // the window reaches the horizon
     // At those levels the reference's patch test lets patches through up to acos(2 cutoff - 1) > 90
     // degrees from an output direction, and then rejects every one of their texels below the
@@ -991,12 +1007,15 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
         else if (matrix) { if (narrow) go(ggx_oct_pairs<false, false, true, true>); else go(ggx_oct_pairs<false, false, true, false>); }
         else          { if (early_records) go(ggx_oct_pairs<false, true>); else go(ggx_oct_pairs<false, false>); }
         if (pass + 1 == pl.passes && ev1) (void)hipEventRecord(ev1, stream);
-        if (pl.reduce_groups > 1)
+        if (pl.accumulate)
+            ggx_oct_reduce<<<dim3(small_blocks, 9, 1), GO_THREADS, 0, stream>>>(
+                d_runs, pl.runs_per_pass, pl.runs_per_pass, 0, n_oct, d_units, oct_count, pass > 0 ? 1u : 0u, d_groups);
+        else if (pl.reduce_groups > 1)
             ggx_oct_reduce<<<dim3(small_blocks, 9, pl.passes > 1 ? pl.runs_per_pass / pl.per_group : pl.reduce_groups),
                              GO_THREADS, 0, stream>>>(d_runs, pl.runs_per_pass, pl.per_group, run_base / pl.per_group, n_oct,
-                                                      d_units, oct_count, d_groups);
+                                                      d_units, oct_count, 0u, d_groups);
     }
-    if (pl.reduce_groups > 1)
+    if (two_stage)
         ggx_oct_final<double><<<dim3(small_blocks, 8), GO_THREADS, 0, stream>>>(
             d_groups, pl.reduce_groups, out_w, pl.tw, d_units, n_oct, oct_count, out_begin, out_count, (float4*)d_out);
     else

@@ -25,6 +25,7 @@ struct Tuning {
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
     int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
     int ggx_rsq = 1;               // ... its weights at narrow lobes through one v_rsq_f32: 1 for inputs from 1024 x 1024, 2 always, 0 never
+    double ggx_sums_mib = 0.0;     // octet GGX kernel: memory a level's sums may take, in MiB (0: 4096); tests use it to reach the plans of huge levels on small ones
     float lamb_split_limit = 16.0f; // ... blocks whose texels cancel by more than this factor are redone with exact weights
 };
 Tuning& tuning();
@@ -125,8 +126,9 @@ struct GgxOctPlan {
     uint32_t runs_per_pass;
     uint32_t per_group;       // consecutive runs per group of the two-stage sum
     uint32_t reduce_groups;   // > 1: the runs are summed in this many groups first
+    bool accumulate;          // every launch adds its runs into ONE set of FP64 sums (levels whose runs do not fit 8 at a time)
     uint32_t out_units;       // 64-octet units this call covers
-    size_t partial_bytes;     // [group][25][out_units*64] double (two-stage sums only) + [run of one pass][25][out_units*64] float
+    size_t partial_bytes;     // [group][25][out_units*64] double (two-stage and accumulated sums) + [run of one pass][25][out_units*64] float
     bool matrix;              // the level's sums go through the matrix pipe (records in their matrix form)
     size_t rec_bytes;         // 7 float4 per input texel octet (matrix form: 144 bytes)
     size_t pn_bytes;          // float4 per patch octet
