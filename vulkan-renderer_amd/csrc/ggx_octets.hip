@@ -871,8 +871,8 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
         uint32_t runs = want < 1 ? 1 : (want > max_runs ? max_runs : want);
         // The sums of one launch's runs (FP32) and of the groups of runs (FP64) together stay below
         // 4 GiB for the whole level.  What that cannot hold at once is launched in several passes
-        // over the same buffer, each followed by its groups' sums (2048 -> 1024: 96 runs as 3 x 32,
-        // 3.0 GB; the same bits as one launch would give).  A group never spans two launches, and a
+        // over the same buffer, each followed by its groups' sums (2048 -> 1024: 120 runs as 3 x 40,
+        // 4.1 GB; the same bits as one launch would give).  A group never spans two launches, and a
         // launch has a multiple of 8 runs, so that the 8 XCDs can own equal shares of them (see
         // ggx_oct_pairs).  Levels too large even for 8 runs at a time (8192 -> 4096: 1.3 GB per run)
         // launch what fits and add every launch into one set of FP64 sums (below).
