@@ -666,9 +666,6 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                             }
                             h0 = go_pack_bf16(f[0], f[1]);
                             h1 = go_pack_bf16(f[2], f[3]);
-                            // (v_dot2c_f32_bf16 with (-1, 0) / (0, -1) would subtract a half of h0 from f in one
-                            // instruction and ran 2 % faster, but the lower pieces it gave were not the exact
-                            // differences: levels came out 1e-2 off)
                             if constexpr (GO_CUT_DOT2 && !CORE) {
                                 // rounded weight minus its upper piece in one instruction, h . (-1, -0) + f
                                 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
