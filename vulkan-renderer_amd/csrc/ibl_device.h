@@ -75,10 +75,34 @@ __device__ __forceinline__ bool ref_cone_test(F3 u, F3 n, float cutoff) {
 // The GGX denominator NoH^2*(a2-1)+1 exactly as the reference rounds it
 // (cube.cpp:267,279-280 with linear.hpp:93-122): half = u + n, NoH = dot(normalize(half), n),
 // every operation in float, no contraction, correctly rounded sqrt and division.
+#ifndef IBL_FAST_CORE
+#define IBL_FAST_CORE 1
+#endif
+// 1 / sqrt(x) * v with the square root and the quotient rounded as IEEE rounds them in all but a
+// vanishing share of the cases, for x in [1/4, 4] (|half|^2 of two unit vectors less than 120 degrees
+// apart): the hardware's 1-ulp estimates and one residual step each (Markstein), 8 instructions
+// where the general correctly rounded sequences take over 20.  The lobe core repeats the
+// reference's arithmetic to reproduce the drift of its rounding, which a rare last-bit difference
+// of either sign does not change.
+__device__ __forceinline__ F3 near_ref_normalize(F3 v) {
+    float x;
+    {
+#pragma clang fp contract(off)
+        x = ref_dot(v, v);
+    }
+    const float r = __builtin_amdgcn_rsqf(x);
+    float y = x * r;
+    y = __builtin_fmaf(__builtin_fmaf(-y, y, x), 0.5f * r, y);          // sqrt(x)
+    float q = __builtin_amdgcn_rcpf(y);
+    q = __builtin_fmaf(__builtin_fmaf(-y, q, 1.0f), q, q);              // 1 / sqrt(x)
+    F3 o = { q * v.x, q * v.y, q * v.z };
+    return o;
+}
+
 __device__ __forceinline__ float ref_ggx_denominator(F3 u, F3 n, float a2m1) {
 #pragma clang fp contract(off)
     F3 half = ref_add(u, n);
-    F3 hn = ref_normalize(half);
+    F3 hn = IBL_FAST_CORE ? near_ref_normalize(half) : ref_normalize(half);
     float noh = ref_dot(hn, n);
     float den = noh * noh;
     den = den * a2m1;
