@@ -434,8 +434,39 @@ def chain_extra(name, args, ibl, rank, world, dist, torch, steps, cpu_seconds):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_command(gpus, argv, environ, port=None):
+    """`python bench.py --gpus N` without a launcher around it: the command and environment of the
+    child that starts one rank per GPU (torch.distributed.run on this node), or None when this
+    process already is a rank (WORLD_SIZE set) or a single GPU is asked for.  Pure: nothing is
+    started and nothing touches the GPU here."""
+    if gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    env = dict(environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "16")                 # the CPU baseline is not run with N > 1
+    env["IBL_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port if port is not None else free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    return cmd, env
+
+
 def main():
     args = parse_args()
+    launch = self_launch_command(args.gpus, sys.argv[1:], os.environ)
+    if launch is not None:
+        # Nothing in this process has touched the GPU (torch is not even imported): the ranks are fresh
+        # child processes, rank 0 prints the one JSON line on the stdout they inherit, and this
+        # process passes their exit status on.
+        import subprocess
+        raise SystemExit(subprocess.run(launch[0], env=launch[1]).returncode)
     import torch
     import torch.distributed as dist
     import vulkan_renderer_amd as vra
@@ -444,9 +475,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     # Rehearsal knobs for a one-GPU box (not used by the driver): all ranks on cuda:0
     # over gloo, since RCCL refuses two ranks on one device.

@@ -139,3 +139,38 @@ def test_one_rank_runs_the_exchange_when_asked():
     p.join(240)
     assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it: the parent spawns torch.distributed.run
+    (one rank per GPU, rendezvous on 127.0.0.1) and passes its arguments on; a process that already is
+    a rank, or a one-GPU run, launches nothing."""
+    import bench
+    argv = ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    cmd, env = bench.self_launch_command(8, argv, {"PATH": "/usr/bin"}, port=23456)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "23456"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == argv
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/usr/bin" and "WORLD_SIZE" not in env
+    assert bench.self_launch_command(1, ["--gpus", "1"], {}) is None
+    assert bench.self_launch_command(8, argv, {"WORLD_SIZE": "8", "RANK": "3"}) is None
+    cmd2, _ = bench.self_launch_command(2, ["--gpus", "2"], {})
+    assert 1024 < int(cmd2[cmd2.index("--master-port") + 1]) < 65536
+
+
+@pytest.mark.timeout(120)
+def test_bench_passes_a_failed_rank_on():
+    """The parent's exit status is the launcher's: a rank that fails (here: no GPU) makes
+    `python bench.py --gpus 2` fail, and nothing is printed on stdout."""
+    import subprocess
+    env = dict(os.environ, IBL_BENCH_BACKEND="gloo", IBL_BENCH_SAME_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-extras", "--no-cpu-baseline", "--workload", "c1"],
+                       env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
