@@ -24,11 +24,6 @@ LUT_TOL = 1e-4          # north-star table tolerance
 # and use a cancellation-free form elsewhere; what is left is ~1e-7 on average and
 # ~1e-5 on single texels that a few very bright inputs dominate.
 GGX_TIGHT = 3e-5
-# One lit texel in a black environment is the worst case of the matrix form's 16-bit factors: no
-# sum averages the 2^-18 cuts of that texel's weight and radiance (mean 1.6e-6, max 2e-5 measured),
-# and 0.06-0.13 % of the RGBE texels land one step off.  Environments with more than a handful of
-# texels under a lobe stay at 1e-6 and 99.99 %.
-BYTE_FRACTION_ONE_TEXEL_MATRIX = 0.998
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -114,9 +109,7 @@ def test_against_committed_pins(ibl, orc, kernel_mode):
         mips = ibl.ggx_mip_levels(w, w, size)
         for m in range(1, mips + 1):
             got = ibl.ggx_level(d_env, w >> m, m, mips).cpu().numpy()
-            bar = BYTE_FRACTION_ONE_TEXEL_MATRIX if (kind == "single" and kernel_mode == "octets") else BYTE_FRACTION
-            _check_cube(orc, got, pins["%s_ggx%d" % (key, m)], tight=GGX_TIGHT, label="%s ggx %d/%d" % (key, m, mips),
-                        byte_fraction=bar)
+            _check_cube(orc, got, pins["%s_ggx%d" % (key, m)], tight=GGX_TIGHT, label="%s ggx %d/%d" % (key, m, mips))
 
 
 # ---- texel directions, codec and box filter: bit-exact ------------------------------
@@ -356,8 +349,79 @@ def test_ggx_special_environments(ibl, orc, kind, kernel_mode):
         want = orc.ggx_level(env, 64 >> m, 64 >> m, m, 2)
         if kind == "const":
             assert np.abs(got[..., :3] / env[0, 0, 0, :3] - 1.0).max() < 1e-6   # cube.cpp:303-305
-        bar = BYTE_FRACTION_ONE_TEXEL_MATRIX if (kind == "single" and kernel_mode == "octets") else BYTE_FRACTION
-        _check_cube(orc, got, want, tight=GGX_TIGHT, byte_fraction=bar)
+        _check_cube(orc, got, want, tight=GGX_TIGHT)
+
+
+_SUN = {}
+
+
+def test_ggx_one_texel_sun_on_a_dim_sky(ibl, orc, kernel_mode):
+    """A sun of one texel, 1e5 times the sky around it, on a 256 x 256/face environment: near the sun's
+    direction the sum of a narrow lobe IS that texel, so nothing averages the rounding of its term.  The
+    matrix form (16-bit factors) hands the patches whose radiance sits in a few texels to the vector pipe
+    (FP32 products), and has to meet the same bars as every other environment: the whole first level
+    (the narrowest lobe) and a band through the sun's neighbourhood of the others."""
+    w = 256
+    if "env" not in _SUN:
+        strip = vra.synth.sun_on_dim_sky_environment(w, ratio=1e5, seed=3)
+        _SUN["env"] = decode_strip(orc, strip)
+        _SUN["want"] = {}
+    env = _SUN["env"]
+    env_d = _dev(ibl, env)
+    flat = env.reshape(-1, 4)[:, :3].max(axis=1)
+    assert flat.max() > 5e4 * np.median(flat)
+    mips = orc.ggx_mip_levels(w, w, 16)
+    assert mips == 4
+    sun = int(np.argmax(flat))                                   # (face, y, x) of the sun, flattened
+    for m in range(1, mips + 1):
+        ow = w >> m
+        n_out = 6 * ow * ow
+        if m == 1:
+            begin, count = 0, n_out
+        else:
+            # the rows of the sun's face around the sun's own row
+            f, y = sun // (w * w), (sun // w) % w
+            row = (f * ow + (y >> m)) * ow
+            begin = max(0, row - 8 * ow)
+            count = min(n_out - begin, 16 * ow)
+        if m not in _SUN["want"]:
+            _SUN["want"][m] = orc.ggx_level(env, ow, ow, m, mips, out_begin=begin, out_count=count)
+        got = ibl.ggx_level(env_d, ow, m, mips, out_begin=begin, out_count=count).cpu().numpy()
+        # (level 1, alpha^2 = 0.0039: where the sun is all a texel sees, the reference's own float rounding
+        # of the GGX denominator, ~1e-7 / d just outside the lobe core the kernels repeat exactly, is that
+        # texel's error -- 6e-5 in every implementation, vector and general kernels included)
+        _check_cube(orc, got, _SUN["want"][m], sel=slice(begin, begin + count), tight=1e-4,
+                    label="sun on a dim sky, level %d/%d (%s)" % (m, mips, kernel_mode))
+
+
+def test_ggx_marked_patches_take_the_vector_form(ibl, orc):
+    """What the marks do, seen from outside: with every patch marked (ggx_few above any patch's texel
+    count) the matrix kernel's launches add up to the vector form's sums (to the rounding of FP32 sums
+    grouped into another number of runs); with none marked (ggx_few 0) and a smooth environment the
+    result is the plain matrix form's."""
+    env = decode_strip(orc, vra.synth.hdr_environment(128, seed=21, sun=False))      # smooth: no light source
+    env_d = _dev(ibl, env)
+    try:
+        ibl.set_tuning("ggx_matrix", 0)
+        vec = ibl.ggx_level(env_d, 64, 1, 3)
+        ibl.set_tuning("ggx_matrix", 1)
+        ibl.set_tuning("ggx_few", 1e9)
+        assert ibl.get_tuning("ggx_few") == 1e9
+        every = ibl.ggx_level(env_d, 64, 1, 3)
+        rel = lambda a, b: float(((a - b).abs() / b.abs().clamp_min(1e-30))[..., :3].max())
+        print("all patches marked vs vector form: max rel %.3g" % rel(every, vec))
+        assert rel(every, vec) < 4e-7
+        ibl.set_tuning("ggx_few", 0)
+        none = ibl.ggx_level(env_d, 64, 1, 3)
+        ibl.set_tuning("ggx_few", 16)
+        default = ibl.ggx_level(env_d, 64, 1, 3)
+        assert ibl.torch.equal(none, default)           # a smooth environment marks nothing
+        assert not ibl.torch.equal(none, vec)
+        print("no patch marked vs vector form: max rel %.3g" % rel(none, vec))
+        assert rel(none, vec) < 2e-6
+    finally:
+        ibl.set_tuning("ggx_matrix", 1)
+        ibl.set_tuning("ggx_few", 16)
 
 
 def test_ggx_counts_match_oracle(ibl, orc, kernel_mode):

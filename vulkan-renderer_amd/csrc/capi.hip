@@ -129,6 +129,7 @@ void read_tuning_once() {
     if (const char* e = getenv("IBL_GGX_CORE")) g_tuning.ggx_core = (float)atof(e);
     if (const char* e = getenv("IBL_GGX_MATRIX")) g_tuning.ggx_matrix = atoi(e);
     if (const char* e = getenv("IBL_GGX_RSQ")) g_tuning.ggx_rsq = atoi(e);
+    if (const char* e = getenv("IBL_GGX_FEW")) g_tuning.ggx_few = (float)atof(e);
 }
 
 // The 64 MiB that ibl_lambertian_static_dev works in instead of allocated workspaces.  Every
@@ -313,6 +314,7 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "ggx_early")) g_tuning.ggx_early = (int)value;
     else if (!strcmp(name, "ggx_matrix")) g_tuning.ggx_matrix = (int)value;
     else if (!strcmp(name, "ggx_rsq")) g_tuning.ggx_rsq = (int)value;
+    else if (!strcmp(name, "ggx_few")) g_tuning.ggx_few = (float)value;
     else if (!strcmp(name, "ggx_sums_mib")) g_tuning.ggx_sums_mib = value;
     else if (!strcmp(name, "bake_rehearse_shards")) g_tuning.bake_rehearse_shards = (int)value;
     else return fail(IBL_EINVAL, "set_tuning: unknown knob %s", name);
@@ -334,6 +336,7 @@ int ibl_get_tuning(const char* name, double* value) {
     else if (!strcmp(name, "ggx_early")) *value = g_tuning.ggx_early;
     else if (!strcmp(name, "ggx_matrix")) *value = g_tuning.ggx_matrix;
     else if (!strcmp(name, "ggx_rsq")) *value = g_tuning.ggx_rsq;
+    else if (!strcmp(name, "ggx_few")) *value = g_tuning.ggx_few;
     else if (!strcmp(name, "ggx_sums_mib")) *value = g_tuning.ggx_sums_mib;
     else if (!strcmp(name, "bake_rehearse_shards")) *value = g_tuning.bake_rehearse_shards;
     else if (!strcmp(name, "general_only")) *value = g_tuning.no_octets ? 1.0 : 0.0;

@@ -71,12 +71,16 @@ __device__ __forceinline__ uint32_t go_global(uint32_t lo, const uint32_t* __res
     return units[lo / GO_UNIT] * GO_UNIT + (lo % GO_UNIT);
 }
 
+// only_marked: the patch octets' table (ggx_oct_mark_patches); records of unmarked patch octets are
+// then left unwritten (nobody reads them).
 __global__ __launch_bounds__(256) void ggx_oct_prep(const float4* __restrict__ env, uint32_t w, uint32_t ps,
-                                                     uint32_t n_rec, float4* __restrict__ rec) {
+                                                     uint32_t n_rec, const float4* __restrict__ only_marked,
+                                                     float4* __restrict__ rec) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_rec) return;
     const uint32_t ps2 = ps * ps, hpw = (w / ps) / 2;
     const uint32_t po = k / ps2, sub = k - po * ps2;
+    if (only_marked && only_marked[po].w == 0.0f) return;
     const uint32_t sy = sub / ps, sx = sub - sy * ps;
     const uint32_t axis = po / (hpw * hpw);
     const uint32_t prem = po - axis * (hpw * hpw);
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(256) void ggx_oct_prep(const float4* __restrict__ e
 
 __global__ __launch_bounds__(256) void ggx_oct_prep_patches(uint32_t pw, uint32_t n_po, float4* __restrict__ pn) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) pn[n_po] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // .x: number of marked patch octets (as bits)
     if (p >= n_po) return;
     const uint32_t hpw = pw / 2;
     const uint32_t axis = p / (hpw * hpw);
@@ -110,6 +115,45 @@ __global__ __launch_bounds__(256) void ggx_oct_prep_patches(uint32_t pw, uint32_
     Texel c = octet_member(axis, pj, pi, 0, pw, pw);
     F3 u = ref_normalize(ref_normal_from(c.face, c.x, c.y, pw, pw));   // cube.cpp:198
     pn[p] = make_float4(u.x, u.y, u.z, 0.0f);
+}
+
+// Patches whose radiance sits in a few texels (a sun of a few texels, one lamp on black) are marked
+// (pn[p].w = 1) and counted (pn[n_po].x).  The matrix form multiplies 16-bit factors; the 2^-18 cut of
+// a term is random and averages out over the texels under a lobe, except where one texel IS the sum.
+// For a patch P and one channel, with S1 = sum of L and S2 = sum of L^2 over its texels, the terms of P
+// contribute at most eps^2 W^2 S2 to an output's squared error and W S1 to its value (W: the lobe's
+// weight over the patch, nearly constant at the scale of a patch), so if S2 <= S1^2 / n_min holds for
+// every patch that takes the matrix form, every output is within eps / sqrt(n_min) whatever the lobe.
+// Patch octets with a member patch that fails this in some channel are walked on the vector pipe with
+// FP32 products instead (ggx_oct_pairs<.., MARKS = 2>), so a lone light gets the vector form's bits.
+// One workgroup per patch octet: 32 threads per member, FP64 sums (L^2 of an RGBE value can leave FP32).
+__global__ __launch_bounds__(256) void ggx_oct_mark_patches(const float4* __restrict__ env, uint32_t w, uint32_t ps,
+                                                             uint32_t n_po, float n_min, float4* __restrict__ pn) {
+    const uint32_t po = blockIdx.x;
+    const uint32_t m = threadIdx.x >> 5, l = threadIdx.x & 31u;
+    const uint32_t ps2 = ps * ps, hpw = (w / ps) / 2;
+    const uint32_t axis = po / (hpw * hpw);
+    const uint32_t prem = po - axis * (hpw * hpw);
+    const uint32_t pj = prem / hpw, pi = prem - pj * hpw;
+    double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
+    for (uint32_t sub = l; sub < ps2; sub += 32) {
+        const uint32_t sy = sub / ps, sx = sub - sy * ps;
+        Texel t = octet_member(axis, pj * ps + sy, pi * ps + sx, m, w, w);
+        const float4 L = env[(t.face * w + t.y) * w + t.x];
+        const double v[3] = { (double)L.x, (double)L.y, (double)L.z };
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s1[k] += v[k]; s2[k] += v[k] * v[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int off = 16; off > 0; off >>= 1) { s1[k] += __shfl_xor(s1[k], off); s2[k] += __shfl_xor(s2[k], off); }
+    bool few = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) few = few || (s2[k] * (double)n_min > s1[k] * s1[k]);
+    if (__syncthreads_or(few ? 1 : 0) && threadIdx.x == 0) {
+        ((float*)(pn + po))[3] = 1.0f;
+        atomicAdd((uint32_t*)(pn + n_po), 1u);
+    }
 }
 
 // A record in scalar registers, and its loads and waits written out.  The outputs are
@@ -351,7 +395,9 @@ __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr
 #ifndef GO_CUT_DOT2
 #define GO_CUT_DOT2 1                    // lower pieces of the weights through v_dot2c_f32_bf16 (0: shift, mask, FMA)
 #endif
-template <bool COUNT, bool EARLY, bool MX = false, bool NARROW = false>
+// MARKS (see ggx_oct_mark_patches): 0 every patch octet; 1 all but the marked ones; 2 only the marked ones,
+// and the run's sums are ADDED to what the launch before (MARKS = 1, same grid) stored.
+template <bool COUNT, bool EARLY, bool MX = false, bool NARROW = false, int MARKS = 0>
 __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_WAVES)) void ggx_oct_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn, const uint32_t* __restrict__ units,
     uint32_t n_po, uint32_t ps2,
@@ -362,6 +408,8 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
     static_assert(GO_WG == 64, "one wave per workgroup: the grid below is counted in waves");
     static_assert(!(MX && (COUNT || EARLY)), "the matrix form neither counts nor drops records");
     static_assert(MX || !NARROW, "NARROW selects the weight form of the matrix kernel");
+    static_assert(MARKS == 0 || (!COUNT && (MX == (MARKS == 1))), "marked patch octets: matrix form without them, vector form on them");
+    if (MARKS == 2 && __float_as_uint(pn[n_po].x) == 0u) return;     // nothing is marked: the sums stand as they are
     // the run's running sums: [sum][lane] (matrix form: rows padded, its fold walks down the sums)
     __shared__ float s_run[GO_SUMS][MX ? GO_WG + 1 : GO_WG];
     const uint32_t lane = threadIdx.x & 63;
@@ -528,6 +576,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
     // An FP32 chunk holds at most 256 terms per sum, all gathered under one pattern:
     // consecutive walks under the same pattern share a chunk while they fit.
     uint32_t acc_tau = 0, acc_terms = 0;      // wave-uniform
+    uint32_t walked_any = 0;                  // wave-uniform (MARKS == 2)
 
     // The level's patch octets are dealt round-robin to the runs (run r owns q = r, r + n_runs,
     // ...), so every run sees every region of the sphere and the waves of one output unit carry
@@ -552,6 +601,8 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                     if (dsum >= wave_thr) cmask |= 1u << tau;
                     if (dsum >= core_cos) cmask |= 256u << tau;
                 }
+                if (MARKS == 1 && c4.w != 0.0f) cmask = 0;
+                if (MARKS == 2 && c4.w == 0.0f) cmask = 0;
             }
             unsigned long long bal = __ballot((cmask & 255u) != 0u);
             while (bal) {                                  // ascending patch order
@@ -577,6 +628,7 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                 uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_v);    // the same in every lane
 
                 if (COUNT && wmask != 0u) tot_visited += ps2;
+                if (MARKS == 2) walked_any |= wmask;
                 const float4* __restrict__ rp = rec + (size_t)po * ps2 * GO_REC;   // wave-uniform
                 // ---- one walk over the patch octet's records per live pattern
                 while (wmask) {
@@ -735,7 +787,13 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
     }
     if (acc_terms != 0u) flush(acc_tau);
 
-    if (lane_valid) {
+    if (MARKS == 2) {
+        if (walked_any != 0u && lane_valid) {
+#pragma unroll
+            for (int k = 0; k < GO_SUMS; k++)
+                partial[((size_t)run_local * GO_SUMS + k) * oct_local + lo] += s_run[k][lane];
+        }
+    } else if (lane_valid) {
 #pragma unroll
         for (int k = 0; k < GO_SUMS; k++)
             partial[((size_t)run_local * GO_SUMS + k) * oct_local + lo] = s_run[k][lane];
@@ -930,8 +988,12 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     const uint32_t stage2 = pl.accumulate ? 1 : (pl.reduce_groups > 1 ? pl.reduce_groups : 0);
     pl.partial_bytes = (size_t)GO_SUMS * oct_count * (pl.runs_per_pass * sizeof(float) + stage2 * sizeof(double));
     // (the counting variant walks the vector form's records: room for the larger of the two)
-    pl.rec_bytes = (size_t)pl.n_po * ps * ps * (pl.matrix ? (size_t)GO_MX_REC_BYTES : GO_REC * sizeof(float4));
-    pl.pn_bytes = (size_t)pl.n_po * sizeof(float4);
+    // Matrix form with marked patch octets (ggx_oct_mark_patches): the matrix form's records, then room for
+    // the vector form's, of which only the marked patch octets' are written and read.
+    pl.marks = pl.matrix && tuning().ggx_few > 0.0f;
+    pl.mx_bytes = pl.matrix ? (size_t)pl.n_po * ps * ps * (size_t)GO_MX_REC_BYTES : 0;
+    pl.rec_bytes = pl.mx_bytes + (!pl.matrix || pl.marks ? (size_t)pl.n_po * ps * ps * GO_REC * sizeof(float4) : 0);
+    pl.pn_bytes = ((size_t)pl.n_po + 1) * sizeof(float4);       // + the count of marked patch octets
     return pl;
 }
 
@@ -942,12 +1004,22 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     const uint32_t ps = pl.lv.patch, ps2 = ps * ps, pw = in_w / ps;
     const uint32_t n_rec = pl.n_po * ps2;
     const bool matrix = pl.matrix && !d_counts;
+    const bool marks = matrix && pl.marks;
+    float4* const d_vec = (float4*)((char*)d_rec + pl.mx_bytes);       // the vector form's records beside the matrix form's
+    ggx_oct_prep_patches<<<(pl.n_po + 255) / 256, 256, 0, stream>>>(pw, pl.n_po, (float4*)d_pn);
+    if (marks) {
+        // a patch of fewer than 2 n_min texels cannot hold n_min equal ones: half its texels then
+        // (a knob value above 256, more than any patch holds, marks every patch: tests)
+        const float n_min = tuning().ggx_few > 256.0f ? tuning().ggx_few : fminf(tuning().ggx_few, 0.5f * (float)ps2);
+        ggx_oct_mark_patches<<<pl.n_po, 256, 0, stream>>>((const float4*)d_env, in_w, ps, pl.n_po, n_min, (float4*)d_pn);
+    }
     if (matrix)
         ggx_mx_prep<<<(n_rec / GO_MX_GROUP * 64 + 255) / 256, 256, 0, stream>>>(
             (const float4*)d_env, in_w, ps, n_rec, (float4*)d_rec, (go_u32x4*)((float4*)d_rec + n_rec));
-    else
-        ggx_oct_prep<<<(n_rec + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, ps, n_rec, (float4*)d_rec);
-    ggx_oct_prep_patches<<<(pl.n_po + 255) / 256, 256, 0, stream>>>(pw, pl.n_po, (float4*)d_pn);
+    if (marks)
+        ggx_oct_prep<<<(n_rec + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, ps, n_rec, (const float4*)d_pn, d_vec);
+    else if (!matrix)
+        ggx_oct_prep<<<(n_rec + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, ps, n_rec, nullptr, (float4*)d_rec);
     const double cut = (double)pl.lv.cutoff;
     const float cmin = (float)fmax(0.0, 2.0 * cut - 1.0);
     const float theta_acc = (float)acos(fmin(1.0, fmax(-1.0, 2.0 * cut - 1.0)));
@@ -961,7 +1033,7 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     // the units: 150 -> 127 ms).  Whole wide-lobe levels with small runs lose 1-3 % with it.  The
     // order changes no sum.
     const double cone = 0.5 * (1.0 - fmax(0.0, 2.0 * (double)pl.lv.cutoff - 1.0));
-    const double run_bytes = (double)pl.rec_bytes / (double)pl.n_runs;
+    const double run_bytes = (double)(pl.matrix ? pl.mx_bytes : pl.rec_bytes) / (double)pl.n_runs;
     uint32_t xcd_runs = (pl.runs_per_pass % 8 == 0 &&
                          (pl.out_units < 3072u || 8.0 * cone < 1.5 || run_bytes > (double)(2u << 20))) ? 1u : 0u;
     if (tuning().ggx_xcd_slices >= 0) xcd_runs = (tuning().ggx_xcd_slices != 0 && pl.runs_per_pass % 8 == 0) ? 1u : 0u;
@@ -995,12 +1067,19 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     for (uint32_t pass = 0; pass < pl.passes; pass++) {
         const uint32_t run_base = pass * pl.runs_per_pass;
         const uint32_t packed = pl.n_runs | (run_base << 15) | (xcd_runs << 31);
-        auto go = [&](auto kernel) {
-            kernel<<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, d_units, pl.n_po,
+        auto go_on = [&](auto kernel, const float4* records) {
+            kernel<<<grid, GO_WG, 0, stream>>>(records, (const float4*)d_pn, d_units, pl.n_po,
                 ps2, out_w, pl.tw, n_oct, oct_count, packed, out_begin, out_count,
                 pl.lv.cutoff, a2m1, cmin, d_counts ? theta_acc : theta_walk, core_thr, d_runs, d_counts);
         };
+        auto go = [&](auto kernel) { go_on(kernel, (const float4*)d_rec); };
         if (d_counts) { if (early_records) go(ggx_oct_pairs<true, true>); else go(ggx_oct_pairs<true, false>); }
+        else if (marks) {
+            // all but the marked patch octets on the matrix pipe, then the marked ones with FP32 products, added
+            // to the same sums by the same waves (its waves leave at once when nothing is marked)
+            if (narrow) go(ggx_oct_pairs<false, false, true, true, 1>); else go(ggx_oct_pairs<false, false, true, false, 1>);
+            go_on(ggx_oct_pairs<false, false, false, false, 2>, d_vec);
+        }
         else if (matrix) { if (narrow) go(ggx_oct_pairs<false, false, true, true>); else go(ggx_oct_pairs<false, false, true, false>); }
         else          { if (early_records) go(ggx_oct_pairs<false, true>); else go(ggx_oct_pairs<false, false>); }
         if (pass + 1 == pl.passes && ev1) (void)hipEventRecord(ev1, stream);

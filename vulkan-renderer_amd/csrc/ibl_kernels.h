@@ -25,6 +25,7 @@ struct Tuning {
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
     int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
     int ggx_rsq = 1;               // ... its weights at narrow lobes through one v_rsq_f32: 1 for inputs from 1024 x 1024, 2 always, 0 never
+    float ggx_few = 16.0f;         // ... patches whose radiance amounts to fewer equal texels than this go to the vector pipe (0: none do)
     double ggx_sums_mib = 0.0;     // octet GGX kernel: memory a level's sums may take, in MiB (0: 4096); tests use it to reach the plans of huge levels on small ones
     float lamb_split_limit = 16.0f; // ... blocks whose texels cancel by more than this factor are redone with exact weights
 };
@@ -130,8 +131,10 @@ struct GgxOctPlan {
     uint32_t out_units;       // 64-octet units this call covers
     size_t partial_bytes;     // [group][25][out_units*64] double (two-stage and accumulated sums) + [run of one pass][25][out_units*64] float
     bool matrix;              // the level's sums go through the matrix pipe (records in their matrix form)
-    size_t rec_bytes;         // 7 float4 per input texel octet (matrix form: 144 bytes)
-    size_t pn_bytes;          // float4 per patch octet
+    bool marks;               // ... except on patch octets whose radiance sits in a few texels (vector pipe, FP32 products)
+    size_t mx_bytes;          // the matrix form's records: 144 bytes per input texel octet (0 without the matrix form)
+    size_t rec_bytes;         // mx_bytes + 7 float4 per input texel octet (vector form; with marks: room for both)
+    size_t pn_bytes;          // float4 per patch octet + one for the count of marked ones
 };
 bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
 uint32_t ggx_oct_tile_edge(uint32_t out_w);

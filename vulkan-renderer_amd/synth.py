@@ -72,3 +72,18 @@ def single_texel_environment(w, face=2, x=None, y=None, value=1000.0):
     y = w // 2 if y is None else y
     out[face, y, x] = encode_rgbe(np.asarray([[value, value * 0.5, value * 0.25]], np.float32))[0]
     return out.reshape(6 * w, w, 4)
+
+
+def sun_on_dim_sky_environment(w, ratio=1e5, seed=3):
+    """-> (6*w, w, 4) uint8 RGBE strip: a smooth, dim sky (radiance 0.02-0.08) and a sun of ONE
+    texel `ratio` times as bright as the sky around it."""
+    rng = np.random.default_rng(seed)
+    d = cube_directions(w)
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    rgb = np.empty(d.shape, np.float64)
+    for c, (a, b) in enumerate(((1.3, 0.4), (0.9, 1.1), (1.7, 2.0))):
+        rgb[..., c] = 0.05 + 0.03 * np.sin(a * np.pi * x + b) * np.cos(a * np.pi * y - b) + 0.01 * z
+    rgb *= 1.0 + 0.02 * rng.standard_normal(size=rgb.shape[:-1] + (1,))
+    face, sy, sx = 2, (5 * w) // 8 + 1, w // 3 + 2
+    rgb[face, sy, sx] = rgb[face, sy, sx] * ratio * np.array([1.0, 0.9, 0.8])
+    return encode_rgbe(rgb).reshape(6 * w, w, 4)
