@@ -189,6 +189,10 @@ class Workload:
             self.matrix = (ibl.get_tuning("ggx_matrix") != 0 and self.env_w >= 64 and not args.ggx_samples
                            and bool(lv1["my_wave_records"]))
             self.matrix_flop_per_launch = None
+            # the same level on the vector pipe alone (ggx_matrix 0): what chain_extra's FP32 run executes
+            self.vector_executed_flop_per_launch = (64.0 * (GGX_FLOP_PER_LANE_WALKED * lv1["my_wave_records"]
+                                                            + GGX_FLOP_PER_LANE_EVALUATED * lv1["my_wave_evaluated"])
+                                                    if lv1["my_wave_records"] else None)
             if lv1["my_wave_records"] and self.matrix:
                 # which weight form level 1 takes: the library's rule (ggx_oct_launch)
                 rsq_knob = ibl.get_tuning("ggx_rsq")
@@ -429,6 +433,28 @@ def chain_extra(name, args, ibl, rank, world, dist, torch, steps, cpu_seconds):
         out[name + "_cpu_sample"] = cb["sample"]
         out[name + "_cpu_sample_max_rel_err"] = cb.get("max_rel_err")
         out[name + "_cpu_sample_rgbe_byte_identical"] = cb.get("rgbe_byte_identical")
+    if getattr(wl, "matrix", False):
+        # Like for like with the reference, which multiplies in FP32: the same chain with the sums on the vector
+        # pipe (ggx_matrix 0), timed the same way in the same run.
+        out[name + "_products"] = ("2 bf16 pieces per factor (16 significant bits) on the matrix pipe; patches whose "
+                                   "radiance sits in a few texels: FP32 on the vector pipe")
+        ibl.set_tuning("ggx_matrix", 0)
+        try:
+            wl.kernel_ms.clear()
+            f_steps = max(1, steps // 2)
+            f_elapsed, f_kernel_ms = run_timed(wl, f_steps, 1, torch, dist, world, ibl.device)
+        finally:
+            ibl.set_tuning("ggx_matrix", 1)
+        f_chain = f_elapsed / f_steps
+        out[name + "_fp32_products"] = "FP32 on the vector pipe throughout (ggx_matrix 0)"
+        out[name + "_fp32_steps"] = f_steps
+        out[name + "_fp32_ms_per_chain"] = round(f_chain * 1e3, 3)
+        out[name + "_fp32_gsamples"] = round(wl.samples / f_chain / 1e9, 1)
+        out[name + "_fp32_level1_kernel_ms"] = round(f_kernel_ms, 4)
+        if wl.vector_executed_flop_per_launch and f_kernel_ms > 0:
+            tf = wl.vector_executed_flop_per_launch / (f_kernel_ms * 1e-3) / 1e12
+            out[name + "_fp32_level1_executed_tflops"] = round(tf, 2)
+            out[name + "_fp32_level1_frac_of_fp32_peak"] = round(tf / FP32_VECTOR_PEAK_TFLOPS, 4)
     del wl
     torch.cuda.empty_cache()
     return out
@@ -558,6 +584,7 @@ def main():
             if tr and world == 1 and not getattr(wl, "ggx_samples", 0):
                 line["roofline"]["traffic"] = tr["bytes"]
                 line["roofline"]["traffic_source"] = tr["source"]
+                line["roofline"]["traffic_measured_in_run"] = False     # a constant from the committed PMC passes
         except OSError:
             pass
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,77 @@
+"""Build-time guards of the hand-written kernels, run on the compiler's output (no GPU needed):
+registers of hand-written scalar loads are not touched while the load is in flight, and the hot
+kernels neither spill vector registers nor use scratch memory."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+CSRC = os.path.join(ROOT, "vulkan-renderer_amd", "csrc")
+
+import check_scalar_loads  # noqa: E402
+import kernel_resources  # noqa: E402
+
+
+def test_checker_sees_a_register_touched_in_flight():
+    body = """
+	s_mov_b32 s4, 0
+	;;#ASMSTART
+	s_load_dwordx4 s[8:11], s[2:3], 0x0
+	;;#ASMEND
+	s_cbranch_scc1 .LBB0_2
+.LBB0_1:
+	v_mov_b32_e32 v0, s12
+	s_branch .LBB0_3
+.LBB0_2:
+	v_writelane_b32 v40, s9, 3
+.LBB0_3:
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	v_mov_b32_e32 v1, s8
+	s_endpgm
+""".splitlines()
+    bad, n = check_scalar_loads.check_function("k", body)
+    assert n == 1
+    assert len(bad) == 1 and bad[0][1] == [9] and "v_writelane" in bad[0][0]
+    # a loop: the load at the bottom is still in flight at the top of the next iteration
+    loop = """
+.LBB0_1:
+	s_add_u32 s20, s8, 1
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	;;#ASMSTART
+	s_load_dwordx2 s[8:9], s[2:3], 0x0
+	;;#ASMEND
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+""".splitlines()
+    bad, n = check_scalar_loads.check_function("k", loop)
+    assert n == 1 and len(bad) == 1 and "s_add_u32" in bad[0][0]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("source", ["ggx_octets.hip", "lambertian_split.hip"])
+def test_hand_written_scalar_loads_are_left_alone(source):
+    lines = check_scalar_loads.assembly(os.path.join(CSRC, source))
+    loads = 0
+    for name, body in check_scalar_loads.functions(lines):
+        bad, n = check_scalar_loads.check_function(name, body)
+        loads += n
+        assert not bad, (name, bad[:3])
+    assert loads >= 10          # the kernels do use them
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("source,kernel", [("ggx_octets.hip", "ggx_oct_pairs"), ("lambertian_split.hip", "ls_pairs")])
+def test_hot_kernels_have_no_scratch(source, kernel):
+    extra = ["-fno-slp-vectorize"] if source == "lambertian_split.hip" else []
+    found = 0
+    for k in kernel_resources.resources(os.path.join(CSRC, source), extra):
+        if kernel in k["name"]:
+            found += 1
+            assert k.get("VGPRs Spill", 0) == 0 and k.get("ScratchSize [bytes/lane]", 0) == 0, k
+    assert found >= 1

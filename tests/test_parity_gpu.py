@@ -332,6 +332,10 @@ def test_lambertian_full_size_properties(ibl, orc, lamb_mode):
 
 @pytest.mark.parametrize("w,min_size", [(16, 8), (64, 16), (64, 4), (128, 16), (48, 12), (96, 20), (100, 16), (40, 10)])
 def test_ggx_chain_parity(ibl, orc, w, min_size, kernel_mode):
+    """Whole chains against the oracle.  100 is not a multiple of its patch size (6): there the reference
+    reads outside its patch table (cube.cpp:196,253), library and oracle share one definition of the
+    result (patch grid of 16 x 16, the last 4 columns and rows left out), and the case only checks that
+    the two agree on it."""
     env, env_d = _env(ibl, orc, w)
     mips = orc.ggx_mip_levels(w, w, min_size)
     assert mips == ibl.ggx_mip_levels(w, w, min_size) and mips >= 1
@@ -397,7 +401,7 @@ def test_ggx_one_texel_sun_on_a_dim_sky(ibl, orc, kernel_mode):
 def test_ggx_marked_patches_take_the_vector_form(ibl, orc):
     """What the marks do, seen from outside: with every patch marked (ggx_few above any patch's texel
     count) the matrix kernel's launches add up to the vector form's sums (to the rounding of FP32 sums
-    grouped into another number of runs); with none marked (ggx_few 0) and a smooth environment the
+    grouped into runs another way); with none marked (ggx_few 0) and a smooth environment the
     result is the plain matrix form's."""
     env = decode_strip(orc, vra.synth.hdr_environment(128, seed=21, sun=False))      # smooth: no light source
     env_d = _dev(ibl, env)
@@ -410,7 +414,7 @@ def test_ggx_marked_patches_take_the_vector_form(ibl, orc):
         every = ibl.ggx_level(env_d, 64, 1, 3)
         rel = lambda a, b: float(((a - b).abs() / b.abs().clamp_min(1e-30))[..., :3].max())
         print("all patches marked vs vector form: max rel %.3g" % rel(every, vec))
-        assert rel(every, vec) < 4e-7
+        assert rel(every, vec) < 1e-6
         ibl.set_tuning("ggx_few", 0)
         none = ibl.ggx_level(env_d, 64, 1, 3)
         ibl.set_tuning("ggx_few", 16)

@@ -19,8 +19,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-corr
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True).stdout
-        return [l.split("(")[0] for l in out.splitlines()]
+        out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
+        return [l.split("(")[0] for l in out] if len(out) == len(names) else names
     except OSError:
         return names
 

@@ -593,9 +593,11 @@ int ggx_check(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_w, 
     if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
         return fail(IBL_EINVAL, "ggx: level %u of %u is out of range", mip_level, mip_levels);
     ibl::GgxLevel lv = ibl::ggx_level_params(mip_level, mip_levels, in_w, in_h);
-    // in_w need not be a multiple of the patch size: like the reference (cube.cpp:175-201,
-    // 251-264), the general kernel then leaves the last in_w % patch columns and rows of a
-    // face out of the quadrature.
+    // in_w need not be a multiple of the patch size.  The library then defines the result itself: a
+    // patch grid of (in_w / patch)^2 per face, the last in_w % patch columns and rows of a face left
+    // out of the quadrature (general kernel).  The reference is undefined for such widths: its patch
+    // table is indexed with (face*H/ps + y)*W/ps + x, divisions left to right (cube.cpp:182,196,253),
+    // which reads outside the table.
     *patch = lv.patch;
     return IBL_OK;
 }

@@ -53,6 +53,7 @@ constexpr int GO_UNIT = 64;             // output octets per wave: the unit of s
 constexpr int GO_REC = 7;              // float4 per texel-octet record
 constexpr int GO_SUMS = 25;             // doubles per (slice, output octet): 8 members x RGB + the weight sum
 constexpr int GO_CHUNK = 256;          // most terms an FP32 chunk sum may hold
+constexpr int GO_MARK_PART = 64;       // records per walk over a marked patch octet (ggx_oct_pairs<.., MARKS = 2>)
 
 // Output octets are numbered tile-major: tiles of tw x tw canonical positions.
 __host__ __device__ inline uint32_t go_tile_edge(uint32_t hw) {
@@ -104,9 +105,11 @@ __global__ __launch_bounds__(256) void ggx_oct_prep(const float4* __restrict__ e
         rec[(size_t)k * GO_REC + q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// Behind the n_po centres: one float4 whose .x holds the number of marked patch octets (as bits), then
+// their list (ggx_oct_mark_patches, ggx_oct_list_marks).
 __global__ __launch_bounds__(256) void ggx_oct_prep_patches(uint32_t pw, uint32_t n_po, float4* __restrict__ pn) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0) pn[n_po] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // .x: number of marked patch octets (as bits)
+    if (p == 0) pn[n_po] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (p >= n_po) return;
     const uint32_t hpw = pw / 2;
     const uint32_t axis = p / (hpw * hpw);
@@ -150,10 +153,33 @@ __global__ __launch_bounds__(256) void ggx_oct_mark_patches(const float4* __rest
     bool few = false;
 #pragma unroll
     for (int k = 0; k < 3; k++) few = few || (s2[k] * (double)n_min > s1[k] * s1[k]);
-    if (__syncthreads_or(few ? 1 : 0) && threadIdx.x == 0) {
-        ((float*)(pn + po))[3] = 1.0f;
-        atomicAdd((uint32_t*)(pn + n_po), 1u);
+    if (__syncthreads_or(few ? 1 : 0) && threadIdx.x == 0) ((float*)(pn + po))[3] = 1.0f;
+}
+
+// The marked patch octets in ascending order behind the centres, and their number: one workgroup, a
+// running count over blocks of 1024 patch octets (the order must not depend on who got there first:
+// it decides which run a patch's terms are added in).
+__global__ __launch_bounds__(1024) void ggx_oct_list_marks(uint32_t n_po, float4* __restrict__ pn) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_base;
+    uint32_t* __restrict__ list = (uint32_t*)(pn + n_po + 1);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < n_po; b += 1024) {
+        const uint32_t p = b + threadIdx.x;
+        const bool m = p < n_po && pn[p].w != 0.0f;
+        const unsigned long long bal = __ballot(m);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = s_base, all = 0;
+        for (uint32_t k = 0; k < 16; k++) { if (k < wv) before += s_wave[k]; all += s_wave[k]; }
+        if (m) list[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = p;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += all;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) ((uint32_t*)(pn + n_po))[0] = s_base;
 }
 
 // A record in scalar registers, and its loads and waits written out.  The outputs are
@@ -409,7 +435,6 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
     static_assert(!(MX && (COUNT || EARLY)), "the matrix form neither counts nor drops records");
     static_assert(MX || !NARROW, "NARROW selects the weight form of the matrix kernel");
     static_assert(MARKS == 0 || (!COUNT && (MX == (MARKS == 1))), "marked patch octets: matrix form without them, vector form on them");
-    if (MARKS == 2 && __float_as_uint(pn[n_po].x) == 0u) return;     // nothing is marked: the sums stand as they are
     // the run's running sums: [sum][lane] (matrix form: rows padded, its fold walks down the sums)
     __shared__ float s_run[GO_SUMS][MX ? GO_WG + 1 : GO_WG];
     const uint32_t lane = threadIdx.x & 63;
@@ -436,6 +461,8 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
         wv = blockIdx.x % n_units;
     }
     const uint32_t run = run_base + run_local;
+    // fewer items (marked patch octet, pattern, stretch of records) than runs: the sums of this run stand as they are
+    if (MARKS == 2 && run >= 8u * ((ps2 + GO_MARK_PART - 1) / GO_MARK_PART) * __float_as_uint(pn[n_po].x)) return;
     const uint32_t lo = wv * GO_UNIT + lane;
     const uint32_t gidx = go_global(lo, units);
     const bool lane_valid = gidx < n_oct;
@@ -578,17 +605,213 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
     uint32_t acc_tau = 0, acc_terms = 0;      // wave-uniform
     uint32_t walked_any = 0;                  // wave-uniform (MARKS == 2)
 
+    // One candidate patch octet: pmask holds the sign patterns whose mirrored patch centre lies inside the
+    // wave's cone (bits 0-7) and, of those, the ones close enough for the lobe core (bits 8-15).
+    // The records of the patch octet a walk covers: all of them, or (MARKS == 2) one stretch.
+    uint32_t w_begin = 0, w_count = ps2;      // wave-uniform
+    auto visit = [&](uint32_t po, uint32_t pmask) __attribute__((always_inline)) {
+        // exact per-lane patch tests (cube.cpp:256-258), one per candidate pattern
+        const float4 c4 = pn[po];
+        uint32_t lane_pass = 0;
+#pragma unroll
+        for (int tau = 0; tau < 8; tau++) {
+            if (pmask & (1u << tau)) {    // wave-uniform
+                F3 pc = { (tau & 1) ? -c4.x : c4.x, (tau & 2) ? -c4.y : c4.y, (tau & 4) ? -c4.z : c4.z };
+                if (lane_valid && ref_cone_test(pc, n, cutoff)) lane_pass |= 1u << tau;
+            }
+        }
+        if (COUNT) tot_tested += (unsigned long long)__popc(lane_pass) * ps2 * 8ull;
+        uint32_t wmask_v = 0;
+#pragma unroll
+        for (int tau = 0; tau < 8; tau++)
+            if (__any((lane_pass >> tau) & 1u)) wmask_v |= 1u << tau;
+        uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_v);    // the same in every lane
+
+        if (COUNT && wmask != 0u) tot_visited += ps2;
+        if (MARKS == 2) walked_any |= wmask;
+        const float4* __restrict__ rp = rec + ((size_t)po * ps2 + w_begin) * GO_REC;   // wave-uniform
+        // ---- one walk over the patch octet's records per live pattern
+        while (wmask) {
+            const uint32_t tau = (uint32_t)__builtin_ctz(wmask);
+            wmask &= wmask - 1;
+            if (acc_terms != 0u && (acc_tau != tau || acc_terms + w_count > (uint32_t)GO_CHUNK)) { flush(acc_tau); acc_terms = 0u; }
+            acc_tau = tau;
+            acc_terms += w_count;
+            // this lane's cutoff for the walk (2 if its patch test failed: weight 0)
+            const float thr = ((lane_pass >> tau) & 1u) ? (COUNT ? cmin : cutoff) : 2.0f;
+            // (EARLY) the lanes whose patch test passed, as a scalar mask: a register per lane
+            // for it would be the one too many
+            const unsigned long long pass_mask = EARLY ? __ballot(((lane_pass >> tau) & 1u) != 0u) : 0ull;
+            const F3 nt = { __uint_as_float(__float_as_uint(n.x) ^ ((tau & 1u) << 31)),
+                            __uint_as_float(__float_as_uint(n.y) ^ ((tau & 2u) << 30)),
+                            __uint_as_float(__float_as_uint(n.z) ^ ((tau & 4u) << 29)) };
+            const bool core_near = ((pmask >> (8u + tau)) & 1u) != 0u;       // wave-uniform
+            // Two scalar register sets (ping-pong, so nothing is copied): the next record is
+            // fetched while the current one is evaluated.  The loads and their waits are
+            // written out (GoRec): scalar loads return out of order, so the only wait is
+            // "all of them", and left to the compiler both the loads and the wait end up
+            // right in front of the first use.
+            GoRec ra, rb;
+            auto walk = [&](auto core_c) __attribute__((always_inline)) {
+                constexpr bool CORE = decltype(core_c)::value;
+                auto eval = [&](const GoRec& src) __attribute__((always_inline)) {
+                    float r[28];
+                    go_unpack(src, r);
+                    float c = nt.x * r[0];
+                    c = fmaf(nt.y, r[1], c);
+                    c = fmaf(nt.z, r[2], c);
+                    if (EARLY && (__ballot(c > cmin) & pass_mask) == 0ull) return;      // weight 0 in every lane
+                    if (COUNT) tot_evaluated += 1;
+                    go_body<COUNT, CORE>(c, r, thr, a2p, kc, nt, acc, accw, n_accepted);
+                };
+                go_rec_load(ra, rp);
+                for (uint32_t e = 0; e < w_count; e += 2) {
+                    go_rec_wait(ra);
+                    go_rec_load(rb, rp + (size_t)min(e + 1, w_count - 1) * GO_REC);
+                    eval(ra);
+                    go_rec_wait(rb);
+                    go_rec_load(ra, rp + (size_t)min(e + 2, w_count - 1) * GO_REC);
+                    if (e + 1 < w_count) eval(rb);
+                }
+                go_rec_wait(ra);       // nothing of this walk is in flight when it ends
+            };
+            auto walk_mx = [&](auto core_c) __attribute__((always_inline)) {
+                constexpr bool CORE = decltype(core_c)::value;
+                const float4* __restrict__ dp = rec + (size_t)po * ps2;                 // wave-uniform
+                const go_u32x4* __restrict__ tp = (const go_u32x4*)(rec + (size_t)n_po * ps2)
+                                                  + (size_t)po * (ps2 / GO_MX_GROUP) * 128 + lane;
+                GoDir4 da, db;
+                // four records: weights, cut into their two bf16 pieces, two records to a register
+                auto quad = [&](const GoDir4& src, uint32_t& h0, uint32_t& h1, uint32_t& m0, uint32_t& m1)
+                                __attribute__((always_inline)) {
+                    float f[4];
+                    if constexpr (!CORE) {
+                        auto f4 = [&](int o) __attribute__((always_inline)) {
+                            const go_f32x4 v = { __uint_as_float(src.v[o]), __uint_as_float(src.v[o + 1]),
+                                                 __uint_as_float(src.v[o + 2]), __uint_as_float(src.v[o + 3]) };
+                            return v;
+                        };
+                        const go_f32x4 nx = { nt.x, nt.x, nt.x, nt.x }, ny = { nt.y, nt.y, nt.y, nt.y },
+                                       nz = { nt.z, nt.z, nt.z, nt.z };
+                        go_f32x4 c = nx * f4(0);
+                        c = __builtin_elementwise_fma(ny, f4(4), c);
+                        c = __builtin_elementwise_fma(nz, f4(8), c);
+                        const go_f32x4 w = go_weight_quad<NARROW>(c, thr, a2p, kc);
+                        f[0] = w.x; f[1] = w.y; f[2] = w.z; f[3] = w.w;
+                    } else {
+                        // near the lobe core: record by record (two exact denominators side by side cost
+                        // more registers than 4 waves per SIMD leave)
+                        uint32_t none = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float ux = __uint_as_float(src.v[e]), uy = __uint_as_float(src.v[4 + e]),
+                                        uz = __uint_as_float(src.v[8 + e]);
+                            float c = nt.x * ux;
+                            c = fmaf(nt.y, uy, c);
+                            c = fmaf(nt.z, uz, c);
+                            f[e] = go_weight<false, true>(c, ux, uy, uz, thr, a2p, kc, nt, none);
+                            // (left alone the compiler evaluates cosine, u and d of all 16 records and their
+                            // exact denominators first and keeps them for the weights: 40 registers more than
+                            // the rest of the kernel needs; the empty statement ends a record before the next)
+                            asm volatile("" : "+v"(f[e]));
+                        }
+                    }
+                    h0 = go_pack_bf16(f[0], f[1]);
+                    h1 = go_pack_bf16(f[2], f[3]);
+                    if constexpr (GO_CUT_DOT2 && !CORE) {
+                        // rounded weight minus its upper piece in one instruction, h . (-1, -0) + f
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        auto sub = [](uint32_t h, uint32_t k, float x) {
+                            return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, h), __builtin_bit_cast(bf16x2, k), x, false);
+                        };
+                        m0 = go_pack_bf16(sub(h0, cut_lo, f[0]), sub(h0, cut_hi, f[1]));
+                        m1 = go_pack_bf16(sub(h1, cut_lo, f[2]), sub(h1, cut_hi, f[3]));
+                    } else {
+                        m0 = go_pack_bf16(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u));
+                        m1 = go_pack_bf16(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
+                    }
+                };
+                go_dir_load(da, dp);
+                for (uint32_t g = 0; g < ps2; g += GO_MX_GROUP) {
+                    const go_u32x4 b_hi = tp[0], b_mid = tp[64];
+                    tp += 128;
+                    uint32_t ah[8], am[8];
+                    go_dir_wait(da);
+                    go_dir_load(db, dp + g + 4);
+                    quad(da, ah[0], ah[1], am[0], am[1]);
+                    go_dir_wait(db);
+                    go_dir_load(da, dp + g + 8);
+                    quad(db, ah[2], ah[3], am[2], am[3]);
+                    go_dir_wait(da);
+                    go_dir_load(db, dp + g + 12);
+                    quad(da, ah[4], ah[5], am[4], am[5]);
+                    go_dir_wait(db);
+                    go_dir_load(da, dp + min(g + 16, ps2 - 4));
+                    quad(db, ah[6], ah[7], am[6], am[7]);
+                    // A operands: rows are the output octets, so the upper lanes' records 0-7 and the lower
+                    // lanes' records 8-15 change places (lanes 32-63 of the first register with lanes 0-31
+                    // of the second)
+                    go_u32x4 a0h, a1h, a0m, a1m;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        auto sh = __builtin_amdgcn_permlane32_swap(ah[i], ah[4 + i], false, false);
+                        a0h[i] = sh[0]; a1h[i] = sh[1];
+                        auto sm = __builtin_amdgcn_permlane32_swap(am[i], am[4 + i], false, false);
+                        a0m[i] = sm[0]; a1m[i] = sm[1];
+                    }
+                    auto bf = [](const go_u32x4& v) { return __builtin_bit_cast(go_bf16x8, v); };
+                    mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0m), bf(b_hi), mx0, 0, 0, 0);
+                    mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1m), bf(b_hi), mx1, 0, 0, 0);
+                    if (GO_MX_TERMS >= 4) {
+                        mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0m), bf(b_mid), mx0, 0, 0, 0);
+                        mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1m), bf(b_mid), mx1, 0, 0, 0);
+                    }
+                    mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_mid), mx0, 0, 0, 0);
+                    mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_mid), mx1, 0, 0, 0);
+                    mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_hi), mx0, 0, 0, 0);
+                    mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_hi), mx1, 0, 0, 0);
+                }
+                go_dir_wait(da);       // nothing of this walk is in flight when it ends
+            };
+            if constexpr (MX) {
+                if (core_near) walk_mx(std::true_type{});
+                else walk_mx(std::false_type{});
+            } else {
+                if (core_near) walk(std::true_type{});
+                else walk(std::false_type{});
+            }
+            if (COUNT) { tot_accepted += (unsigned long long)n_accepted * 8ull; n_accepted = 0; tot_walked += ps2; }
+        }
+    };
+
+    if constexpr (MARKS == 2) {
+        // The marked patch octets, in ascending order, times the 8 sign patterns times stretches of 64
+        // records are dealt to the runs one item at a time: a handful of marked patches -- the usual case --
+        // is then one short walk for each of many waves, not eight long ones after each other for a few (a
+        // lone wave waits out the latency of every record it loads).
+        const uint32_t* __restrict__ list = (const uint32_t*)(pn + n_po + 1);
+        const uint32_t parts = (ps2 + GO_MARK_PART - 1) / GO_MARK_PART;
+        const uint32_t n_items = 8u * parts * __float_as_uint(pn[n_po].x);
+        for (uint32_t it = run; it < n_items; it += n_runs) {
+            const uint32_t part = it % parts, pt = it / parts;
+            const uint32_t po = list[pt >> 3], tau = pt & 7u;
+            w_begin = part * GO_MARK_PART;
+            w_count = min(ps2 - w_begin, (uint32_t)GO_MARK_PART);
+            const float4 c4 = pn[po];
+            const float dsum = ((tau & 1u) ? -c4.x : c4.x) * axx + ((tau & 2u) ? -c4.y : c4.y) * axy
+                               + ((tau & 4u) ? -c4.z : c4.z) * axz;
+            if (!(dsum >= wave_thr)) continue;
+            visit(po, (1u << tau) | (dsum >= core_cos ? (256u << tau) : 0u));
+        }
+    } else {
     // The level's patch octets are dealt round-robin to the runs (run r owns q = r, r + n_runs,
     // ...), so every run sees every region of the sphere and the waves of one output unit carry
     // equal shares of its cone.
-    {
         const uint32_t n_subsets = n_runs, subset = run;
         const uint32_t my_count = (n_po + n_subsets - 1 - subset) / n_subsets;
 
         for (uint32_t base = 0; base < my_count; base += 64) {
-            // ---- candidates among the next 64 patch octets of the subset: sign patterns whose
-            //      mirrored patch centre lies inside the wave's cone (bits 0-7), and of those the
-            //      ones close enough for the lobe core (bits 8-15)
+            // ---- candidates among the next 64 patch octets of the subset
             const uint32_t qi = base + lane;
             const uint32_t q = qi * n_subsets + subset;
             uint32_t cmask = 0;
@@ -602,186 +825,12 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
                     if (dsum >= core_cos) cmask |= 256u << tau;
                 }
                 if (MARKS == 1 && c4.w != 0.0f) cmask = 0;
-                if (MARKS == 2 && c4.w == 0.0f) cmask = 0;
             }
             unsigned long long bal = __ballot((cmask & 255u) != 0u);
             while (bal) {                                  // ascending patch order
                 const int src = __ffsll((long long)bal) - 1;
                 bal &= bal - 1;
-                const uint32_t po = __builtin_amdgcn_readlane(q, src);
-                const uint32_t pmask = __builtin_amdgcn_readlane(cmask, src);
-                // exact per-lane patch tests (cube.cpp:256-258), one per candidate pattern
-                const float4 c4 = pn[po];
-                uint32_t lane_pass = 0;
-#pragma unroll
-                for (int tau = 0; tau < 8; tau++) {
-                    if (pmask & (1u << tau)) {    // wave-uniform
-                        F3 pc = { (tau & 1) ? -c4.x : c4.x, (tau & 2) ? -c4.y : c4.y, (tau & 4) ? -c4.z : c4.z };
-                        if (lane_valid && ref_cone_test(pc, n, cutoff)) lane_pass |= 1u << tau;
-                    }
-                }
-                if (COUNT) tot_tested += (unsigned long long)__popc(lane_pass) * ps2 * 8ull;
-                uint32_t wmask_v = 0;
-#pragma unroll
-                for (int tau = 0; tau < 8; tau++)
-                    if (__any((lane_pass >> tau) & 1u)) wmask_v |= 1u << tau;
-                uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_v);    // the same in every lane
-
-                if (COUNT && wmask != 0u) tot_visited += ps2;
-                if (MARKS == 2) walked_any |= wmask;
-                const float4* __restrict__ rp = rec + (size_t)po * ps2 * GO_REC;   // wave-uniform
-                // ---- one walk over the patch octet's records per live pattern
-                while (wmask) {
-                    const uint32_t tau = (uint32_t)__builtin_ctz(wmask);
-                    wmask &= wmask - 1;
-                    if (acc_terms != 0u && (acc_tau != tau || acc_terms + ps2 > (uint32_t)GO_CHUNK)) { flush(acc_tau); acc_terms = 0u; }
-                    acc_tau = tau;
-                    acc_terms += ps2;
-                    // this lane's cutoff for the walk (2 if its patch test failed: weight 0)
-                    const float thr = ((lane_pass >> tau) & 1u) ? (COUNT ? cmin : cutoff) : 2.0f;
-                    // (EARLY) the lanes whose patch test passed, as a scalar mask: a register per lane
-                    // for it would be the one too many
-                    const unsigned long long pass_mask = EARLY ? __ballot(((lane_pass >> tau) & 1u) != 0u) : 0ull;
-                    const F3 nt = { __uint_as_float(__float_as_uint(n.x) ^ ((tau & 1u) << 31)),
-                                    __uint_as_float(__float_as_uint(n.y) ^ ((tau & 2u) << 30)),
-                                    __uint_as_float(__float_as_uint(n.z) ^ ((tau & 4u) << 29)) };
-                    const bool core_near = ((pmask >> (8u + tau)) & 1u) != 0u;       // wave-uniform
-                    // Two scalar register sets (ping-pong, so nothing is copied): the next record is
-                    // fetched while the current one is evaluated.  The loads and their waits are
-                    // written out (GoRec): scalar loads return out of order, so the only wait is
-                    // "all of them", and left to the compiler both the loads and the wait end up
-                    // right in front of the first use.
-                    GoRec ra, rb;
-                    auto walk = [&](auto core_c) __attribute__((always_inline)) {
-                        constexpr bool CORE = decltype(core_c)::value;
-                        auto eval = [&](const GoRec& src) __attribute__((always_inline)) {
-                            float r[28];
-                            go_unpack(src, r);
-                            float c = nt.x * r[0];
-                            c = fmaf(nt.y, r[1], c);
-                            c = fmaf(nt.z, r[2], c);
-                            if (EARLY && (__ballot(c > cmin) & pass_mask) == 0ull) return;      // weight 0 in every lane
-                            if (COUNT) tot_evaluated += 1;
-                            go_body<COUNT, CORE>(c, r, thr, a2p, kc, nt, acc, accw, n_accepted);
-                        };
-                        go_rec_load(ra, rp);
-                        for (uint32_t e = 0; e < ps2; e += 2) {
-                            go_rec_wait(ra);
-                            go_rec_load(rb, rp + (size_t)min(e + 1, ps2 - 1) * GO_REC);
-                            eval(ra);
-                            go_rec_wait(rb);
-                            go_rec_load(ra, rp + (size_t)min(e + 2, ps2 - 1) * GO_REC);
-                            if (e + 1 < ps2) eval(rb);
-                        }
-                        go_rec_wait(ra);       // nothing of this walk is in flight when it ends
-                    };
-                    auto walk_mx = [&](auto core_c) __attribute__((always_inline)) {
-                        constexpr bool CORE = decltype(core_c)::value;
-                        const float4* __restrict__ dp = rec + (size_t)po * ps2;                 // wave-uniform
-                        const go_u32x4* __restrict__ tp = (const go_u32x4*)(rec + (size_t)n_po * ps2)
-                                                          + (size_t)po * (ps2 / GO_MX_GROUP) * 128 + lane;
-                        GoDir4 da, db;
-                        // four records: weights, cut into their two bf16 pieces, two records to a register
-                        auto quad = [&](const GoDir4& src, uint32_t& h0, uint32_t& h1, uint32_t& m0, uint32_t& m1)
-                                        __attribute__((always_inline)) {
-                            float f[4];
-                            if constexpr (!CORE) {
-                                auto f4 = [&](int o) __attribute__((always_inline)) {
-                                    const go_f32x4 v = { __uint_as_float(src.v[o]), __uint_as_float(src.v[o + 1]),
-                                                         __uint_as_float(src.v[o + 2]), __uint_as_float(src.v[o + 3]) };
-                                    return v;
-                                };
-                                const go_f32x4 nx = { nt.x, nt.x, nt.x, nt.x }, ny = { nt.y, nt.y, nt.y, nt.y },
-                                               nz = { nt.z, nt.z, nt.z, nt.z };
-                                go_f32x4 c = nx * f4(0);
-                                c = __builtin_elementwise_fma(ny, f4(4), c);
-                                c = __builtin_elementwise_fma(nz, f4(8), c);
-                                const go_f32x4 w = go_weight_quad<NARROW>(c, thr, a2p, kc);
-                                f[0] = w.x; f[1] = w.y; f[2] = w.z; f[3] = w.w;
-                            } else {
-                                // near the lobe core: record by record (two exact denominators side by side cost
-                                // more registers than 4 waves per SIMD leave)
-                                uint32_t none = 0;
-#pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    const float ux = __uint_as_float(src.v[e]), uy = __uint_as_float(src.v[4 + e]),
-                                                uz = __uint_as_float(src.v[8 + e]);
-                                    float c = nt.x * ux;
-                                    c = fmaf(nt.y, uy, c);
-                                    c = fmaf(nt.z, uz, c);
-                                    f[e] = go_weight<false, true>(c, ux, uy, uz, thr, a2p, kc, nt, none);
-                                    // (left alone the compiler evaluates cosine, u and d of all 16 records and their
-                                    // exact denominators first and keeps them for the weights: 40 registers more than
-                                    // the rest of the kernel needs; the empty statement ends a record before the next)
-                                    asm volatile("" : "+v"(f[e]));
-                                }
-                            }
-                            h0 = go_pack_bf16(f[0], f[1]);
-                            h1 = go_pack_bf16(f[2], f[3]);
-                            if constexpr (GO_CUT_DOT2 && !CORE) {
-                                // rounded weight minus its upper piece in one instruction, h . (-1, -0) + f
-                                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                                auto sub = [](uint32_t h, uint32_t k, float x) {
-                                    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, h), __builtin_bit_cast(bf16x2, k), x, false);
-                                };
-                                m0 = go_pack_bf16(sub(h0, cut_lo, f[0]), sub(h0, cut_hi, f[1]));
-                                m1 = go_pack_bf16(sub(h1, cut_lo, f[2]), sub(h1, cut_hi, f[3]));
-                            } else {
-                                m0 = go_pack_bf16(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u));
-                                m1 = go_pack_bf16(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
-                            }
-                        };
-                        go_dir_load(da, dp);
-                        for (uint32_t g = 0; g < ps2; g += GO_MX_GROUP) {
-                            const go_u32x4 b_hi = tp[0], b_mid = tp[64];
-                            tp += 128;
-                            uint32_t ah[8], am[8];
-                            go_dir_wait(da);
-                            go_dir_load(db, dp + g + 4);
-                            quad(da, ah[0], ah[1], am[0], am[1]);
-                            go_dir_wait(db);
-                            go_dir_load(da, dp + g + 8);
-                            quad(db, ah[2], ah[3], am[2], am[3]);
-                            go_dir_wait(da);
-                            go_dir_load(db, dp + g + 12);
-                            quad(da, ah[4], ah[5], am[4], am[5]);
-                            go_dir_wait(db);
-                            go_dir_load(da, dp + min(g + 16, ps2 - 4));
-                            quad(db, ah[6], ah[7], am[6], am[7]);
-                            // A operands: rows are the output octets, so the upper lanes' records 0-7 and the lower
-                            // lanes' records 8-15 change places (lanes 32-63 of the first register with lanes 0-31
-                            // of the second)
-                            go_u32x4 a0h, a1h, a0m, a1m;
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                auto sh = __builtin_amdgcn_permlane32_swap(ah[i], ah[4 + i], false, false);
-                                a0h[i] = sh[0]; a1h[i] = sh[1];
-                                auto sm = __builtin_amdgcn_permlane32_swap(am[i], am[4 + i], false, false);
-                                a0m[i] = sm[0]; a1m[i] = sm[1];
-                            }
-                            auto bf = [](const go_u32x4& v) { return __builtin_bit_cast(go_bf16x8, v); };
-                            mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0m), bf(b_hi), mx0, 0, 0, 0);
-                            mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1m), bf(b_hi), mx1, 0, 0, 0);
-                            if (GO_MX_TERMS >= 4) {
-                                mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0m), bf(b_mid), mx0, 0, 0, 0);
-                                mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1m), bf(b_mid), mx1, 0, 0, 0);
-                            }
-                            mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_mid), mx0, 0, 0, 0);
-                            mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_mid), mx1, 0, 0, 0);
-                            mx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_hi), mx0, 0, 0, 0);
-                            mx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_hi), mx1, 0, 0, 0);
-                        }
-                        go_dir_wait(da);       // nothing of this walk is in flight when it ends
-                    };
-                    if constexpr (MX) {
-                        if (core_near) walk_mx(std::true_type{});
-                        else walk_mx(std::false_type{});
-                    } else {
-                        if (core_near) walk(std::true_type{});
-                        else walk(std::false_type{});
-                    }
-                    if (COUNT) { tot_accepted += (unsigned long long)n_accepted * 8ull; n_accepted = 0; tot_walked += ps2; }
-                }
+                visit(__builtin_amdgcn_readlane(q, src), __builtin_amdgcn_readlane(cmask, src));
             }
         }
     }
@@ -993,7 +1042,7 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     pl.marks = pl.matrix && tuning().ggx_few > 0.0f;
     pl.mx_bytes = pl.matrix ? (size_t)pl.n_po * ps * ps * (size_t)GO_MX_REC_BYTES : 0;
     pl.rec_bytes = pl.mx_bytes + (!pl.matrix || pl.marks ? (size_t)pl.n_po * ps * ps * GO_REC * sizeof(float4) : 0);
-    pl.pn_bytes = ((size_t)pl.n_po + 1) * sizeof(float4);       // + the count of marked patch octets
+    pl.pn_bytes = ((size_t)pl.n_po + 1) * sizeof(float4) + (size_t)pl.n_po * sizeof(uint32_t);    // + number and list of the marked patch octets
     return pl;
 }
 
@@ -1012,6 +1061,7 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
         // (a knob value above 256, more than any patch holds, marks every patch: tests)
         const float n_min = tuning().ggx_few > 256.0f ? tuning().ggx_few : fminf(tuning().ggx_few, 0.5f * (float)ps2);
         ggx_oct_mark_patches<<<pl.n_po, 256, 0, stream>>>((const float4*)d_env, in_w, ps, pl.n_po, n_min, (float4*)d_pn);
+        ggx_oct_list_marks<<<1, 1024, 0, stream>>>(pl.n_po, (float4*)d_pn);
     }
     if (matrix)
         ggx_mx_prep<<<(n_rec / GO_MX_GROUP * 64 + 255) / 256, 256, 0, stream>>>(
