@@ -141,9 +141,11 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
  * FP64.  On mirror-symmetric face sizes with an input of 64 x 64 and more the products
  * weight x radiance of those first sums are formed on the matrix pipe from two bf16 pieces of each
  * factor (16 significant bits; knob "ggx_matrix", 1 by default, 0 keeps them in FP32 on the vector
- * pipe): measured against the FP32 form <= 1e-6 on environments where more than a handful of
- * texels lie under a lobe (99.99 % of the RGBE texels identical), and mean 1.6e-6 / at most 2e-5
- * for a single lit texel in a black environment, where nothing averages the cuts.  On inputs of
+ * pipe).  The 2^-18 cut of a term is random and averages out over the texels under a lobe; where it
+ * could not -- patches whose radiance amounts to fewer than 16 equal texels in some channel (knob
+ * "ggx_few"; a sun of a few texels, one lamp on black) -- the patch is walked with FP32 products on
+ * the vector pipe instead, by a second launch that adds into the same sums.  Measured against the
+ * FP32 form: <= 1e-6, 99.99 % of the RGBE texels identical, lone lights included.  On inputs of
  * 1024 x 1024 and more, at the levels whose acceptance window ends above the horizon
  * (cutoff > 1/2), that form takes sqrt(NoH^2) / denom^2 of cube.cpp:280-281 as one reciprocal
  * square root (knob "ggx_rsq": 1 this rule, 0 never, 2 at every such level; the two forms agree
@@ -267,6 +269,15 @@ int ibl_mirror_reflect_camera(const float* transform, const float* camera, float
 
 /* ---- host-buffer entry points -------------------------------------------- */
 
+/* The reference's functions on caller-owned host buffers, blocking: integrateLambertian's and
+ * integrateGGX's texel loops (cube.cpp:95-133, 240-313) and generateGGXLUT's cell loop
+ * (cube.cpp:346-385), minus encoding, files and printing.  As the reference's one call uses every
+ * core of the host (cube.cpp:95,240), these use every initialised device: after ibl_init_all(n)
+ * the output is split into n shards (the partition of the *_shard_dev entry points; ranges of cells
+ * for the table), one host thread per device copies the input to its device, computes its shard
+ * and puts its texels into `out`.  The floats returned do not depend on the number of devices.
+ * ibl_rgbe_*, ibl_downscale and ibl_png_filter_rows are streaming passes and stay on the current
+ * device. */
 int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* out);
 int ibl_ggx_level(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h,
                   uint32_t mip_level, uint32_t mip_levels, float* out);
@@ -281,8 +292,12 @@ int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* o
 
 /* Progress of the ibl_bake_* calls: fn(cube, user) is called, from a thread of the library,
  * each time a cube's bytes have arrived in the caller's buffer -- cube 0 is the Lambertian
- * cube, cube m > 0 GGX level m, in that order -- where the reference draws its progress bars
- * (cube.cpp:76-92,131-132,220-236,311-312).  NULL switches it off. */
+ * cube, cube m > 0 GGX level m -- where the reference draws its progress bars
+ * (cube.cpp:76-92,131-132,220-236,311-312).  Calls never overlap.  On one device they come in
+ * that order, each while the device is already baking the next cube, so whatever the callback
+ * does with a finished cube (compress it, write its file) costs the bake no time; on several
+ * devices the thread that delivers a cube's last shard reports it, in the order the cubes
+ * complete.  NULL switches it off. */
 typedef void (*ibl_progress_fn)(int cube, void* user);
 int ibl_set_progress(ibl_progress_fn fn, void* user);
 
@@ -296,8 +311,13 @@ int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, 
                   uint8_t* lambertian_out, uint8_t* ggx_out);
 /* With several devices initialised (ibl_init_all) the three bake calls run one host thread per
  * device: every device decodes the strip, computes its shard of every cube (the partition of
- * the *_shard_dev entry points), packs its texels and hands them to the host, which assembles
- * the cubes.  The bytes returned do not depend on the number of devices. */
+ * the *_shard_dev entry points), packs its texels and hands them to the host, where they are
+ * put in place; the thread that brings a cube's last shard finishes the cube (PNG scanlines: it
+ * filters the assembled texels on its own device) and reports it.  The bytes returned do not
+ * depend on the number of devices.  A machine with one GPU rehearses this path with the knobs
+ * "bake_rehearse_shards" = n (the device plays n shards in turn) and "bake_rehearse_concurrent" = 1
+ * (all n at once, every thread with workspaces and a stream of its own); the host-buffer entry
+ * points above follow the same knobs. */
 
 /* The same bake with the GGX levels computed by the sampled mode above (ggx_samples > 0;
  * 0 selects the quadrature, i.e. ibl_bake_rgbe).  No counterpart in the reference. */
@@ -322,7 +342,7 @@ int ibl_set_kernel_mode(int general_only);
 /* Launch-shape knobs of the kernels (slice counts, grid orders; the names are the
  * library's own, the tools under tools/ use them).  They change speed only, except
  * the slice counts, which fix the order of the sums and with it the last bits, and
- * "lamb_split" / "ggx_matrix" / "ggx_rsq", which choose between two forms of the arithmetic (see
+ * "lamb_split" / "ggx_matrix" / "ggx_few" / "ggx_rsq", which choose between two forms of the arithmetic (see
  * ibl_lambertian_dev and ibl_ggx_level_dev). */
 int ibl_set_tuning(const char* name, double value);
 /* The current value of a knob ("general_only" reads back ibl_set_kernel_mode). */

@@ -932,12 +932,15 @@ def test_bake_png_rows_is_bake_rgbe_filtered(ibl, orc):
     assert none == []
 
 
-def test_bake_on_several_shards_returns_the_same_bytes(ibl, orc):
+@pytest.mark.parametrize("concurrent", [0, 1])
+def test_bake_on_several_shards_returns_the_same_bytes(ibl, orc, concurrent):
     """The path ibl_bake_* takes when several devices are initialised (one host thread per
-    device: shard kernels, encode, pack, copy, scatter on the host), rehearsed on one GPU by
-    letting it play 1, 3 and 8 shards in turn: same bytes as the one-device bake, for pixels
-    and for PNG scanlines, quadrature and sampled GGX, and the progress callback names every
-    cube once, in order."""
+    device: shard kernels, encode, pack, copy, scatter on the host; the thread that delivers a cube's
+    last shard finishes and reports it), rehearsed on one GPU by letting it play 3 and 8 shards --
+    in turn on the device's own state, or (concurrent) all at once, every thread on a stand-in
+    state with its own workspaces and stream, which is the shape of the real thing: same bytes as
+    the one-device bake, for pixels and for PNG scanlines, quadrature and sampled GGX, and the
+    progress callback names every cube once -- before the bake call returns, in PNG mode too."""
     import ctypes
     strip = vra.synth.hdr_environment(64, seed=23)
     want_lam, want_levels = ibl.bake_rgbe(strip, input_downscale=2, cubemap_size=16)
@@ -945,24 +948,25 @@ def test_bake_on_several_shards_returns_the_same_bytes(ibl, orc):
     want_s = ibl.bake_rgbe(strip, cubemap_size=16, ggx_samples=64)
     seen = []
     cb = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)(lambda cube, user: seen.append(cube))
+    order = (lambda got: got == [0, 1, 2]) if not concurrent else (lambda got: sorted(got) == [0, 1, 2])
     try:
-        for shards in (1, 3, 8):
-            ibl.set_tuning("bake_rehearse_shards", shards if shards > 1 else 0)
-            if shards == 1:
-                continue
+        ibl.set_tuning("bake_rehearse_concurrent", concurrent)
+        for shards in (3, 8):
+            ibl.set_tuning("bake_rehearse_shards", shards)
             assert ibl.lib.ibl_set_progress(ctypes.cast(cb, ctypes.c_void_p), None) == 0
-            del seen[:]
-            lam, levels = ibl.bake_rgbe(strip, input_downscale=2, cubemap_size=16)
-            assert seen == [0, 1, 2]
-            np.testing.assert_array_equal(lam, want_lam)
-            for a, b in zip(levels, want_levels):
-                np.testing.assert_array_equal(a, b)
-            del seen[:]
-            lam_rows, level_rows = ibl.bake_png_rows(strip, input_downscale=2, cubemap_size=16)
-            assert seen == [0, 1, 2]
-            np.testing.assert_array_equal(lam_rows, want_rows[0])
-            for a, b in zip(level_rows, want_rows[1]):
-                np.testing.assert_array_equal(a, b)
+            for _ in range(3 if concurrent else 1):        # (threads racing: more than one go)
+                del seen[:]
+                lam, levels = ibl.bake_rgbe(strip, input_downscale=2, cubemap_size=16)
+                assert order(seen), seen
+                np.testing.assert_array_equal(lam, want_lam)
+                for a, b in zip(levels, want_levels):
+                    np.testing.assert_array_equal(a, b)
+                del seen[:]
+                lam_rows, level_rows = ibl.bake_png_rows(strip, input_downscale=2, cubemap_size=16)
+                assert order(seen), seen
+                np.testing.assert_array_equal(lam_rows, want_rows[0])
+                for a, b in zip(level_rows, want_rows[1]):
+                    np.testing.assert_array_equal(a, b)
             lam_s, levels_s = ibl.bake_rgbe(strip, cubemap_size=16, ggx_samples=64)
             np.testing.assert_array_equal(lam_s, want_s[0])
             for a, b in zip(levels_s, want_s[1]):
@@ -971,13 +975,83 @@ def test_bake_on_several_shards_returns_the_same_bytes(ibl, orc):
             assert none == [] and only.shape == (96, 16, 4)
     finally:
         ibl.set_tuning("bake_rehearse_shards", 0)
+        ibl.set_tuning("bake_rehearse_concurrent", 0)
         ibl.lib.ibl_set_progress(None, None)
-    # the one-device bake reports progress too
+    # the one-device bake reports progress too, every cube while the next one is being baked
     ibl.lib.ibl_set_progress(ctypes.cast(cb, ctypes.c_void_p), None)
     del seen[:]
     ibl.bake_rgbe(strip, input_downscale=2, cubemap_size=16)
     ibl.lib.ibl_set_progress(None, None)
     assert seen == [0, 1, 2]
+
+
+def test_progress_arrives_while_the_bake_is_running(ibl, orc):
+    """A cube is reported as soon as it is complete, not when the bake call returns: the callback of
+    cube k finds cube k's bytes final and is called while later cubes are still to come (the call
+    count at that moment is k + 1), on one device, on shards in turn, and on concurrent shards in
+    PNG mode, where the thread that delivers the last shard filters the cube itself."""
+    import ctypes
+    strip = vra.synth.hdr_environment(64, seed=29)
+    want_rows = ibl.bake_png_rows(strip, cubemap_size=16)
+    state = {"calls": [], "snap": {}}
+    out = {}
+
+    def on_done(cube, user):
+        state["calls"].append(cube)
+        if "lam" in out:
+            buf = out["lam"] if cube == 0 else out["ggx"][cube - 1]
+            state["snap"][cube] = buf.copy()
+    cb = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)(on_done)
+    try:
+        ibl.lib.ibl_set_progress(ctypes.cast(cb, ctypes.c_void_p), None)
+        for shards, concurrent in ((0, 0), (3, 0), (4, 1)):
+            ibl.set_tuning("bake_rehearse_shards", shards)
+            ibl.set_tuning("bake_rehearse_concurrent", concurrent)
+            state["calls"], state["snap"] = [], {}
+            lam_rows, level_rows = ibl.bake_png_rows(strip, cubemap_size=16, _expose=out)
+            assert sorted(state["calls"]) == [0, 1, 2]
+            np.testing.assert_array_equal(lam_rows, want_rows[0])
+            np.testing.assert_array_equal(state["snap"][0], want_rows[0])
+            for k, b in enumerate(want_rows[1]):
+                np.testing.assert_array_equal(level_rows[k], b)
+                np.testing.assert_array_equal(state["snap"][k + 1], b)     # final when it was reported
+    finally:
+        ibl.set_tuning("bake_rehearse_shards", 0)
+        ibl.set_tuning("bake_rehearse_concurrent", 0)
+        ibl.lib.ibl_set_progress(None, None)
+
+
+def test_host_entry_points_use_every_device(ibl, orc):
+    """ibl_lambertian / ibl_ggx_level / ibl_brdf_lut / ibl_ggx_level_sampled on host buffers split their
+    output over all initialised devices (the reference's one call uses every core, cube.cpp:95,240)
+    and return the floats of the one-device call; rehearsed on one GPU with 3 and 8 shards, in turn and
+    at once, on sizes served by the octet kernels and by the general ones."""
+    env = decode_strip(orc, vra.synth.hdr_environment(64, seed=37))
+    env30 = decode_strip(orc, vra.synth.hdr_environment(30, seed=38))
+    want = {
+        "lam": ibl.lambertian_host(env, 16), "lam30": ibl.lambertian_host(env30, 5),
+        "ggx1": ibl.ggx_level_host(env, 32, 1, 2), "ggx2": ibl.ggx_level_host(env, 16, 2, 2),
+        "ggx30": ibl.ggx_level_host(env30, 15, 1, 1),
+        "lut": ibl.brdf_lut_host(32, 48, 8, seed=5), "sampled": ibl.ggx_level_sampled_host(env, 16, 2, 2, 32),
+    }
+    np.testing.assert_array_equal(want["lam"], ibl.lambertian(_dev(ibl, env), 16).cpu().numpy())
+    try:
+        for shards, concurrent in ((3, 0), (8, 0), (3, 1), (8, 1)):
+            ibl.set_tuning("bake_rehearse_shards", shards)
+            ibl.set_tuning("bake_rehearse_concurrent", concurrent)
+            got = {
+                "lam": ibl.lambertian_host(env, 16), "lam30": ibl.lambertian_host(env30, 5),
+                "ggx1": ibl.ggx_level_host(env, 32, 1, 2), "ggx2": ibl.ggx_level_host(env, 16, 2, 2),
+                "ggx30": ibl.ggx_level_host(env30, 15, 1, 1),
+                "lut": ibl.brdf_lut_host(32, 48, 8, seed=5), "sampled": ibl.ggx_level_sampled_host(env, 16, 2, 2, 32),
+            }
+            for k in want:
+                np.testing.assert_array_equal(got[k], want[k], err_msg="%s on %d shards (concurrent %d)" % (k, shards, concurrent))
+        with pytest.raises(vra.IblError):
+            ibl.ggx_level_host(env[:, :8, :8], 4, 1, 1)          # 8 x 8 input: rejected on the sharded path too
+    finally:
+        ibl.set_tuning("bake_rehearse_shards", 0)
+        ibl.set_tuning("bake_rehearse_concurrent", 0)
 
 
 def test_timing_ring_and_knob_readback(ibl, orc):

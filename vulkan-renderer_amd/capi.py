@@ -487,8 +487,10 @@ class Ibl:
         return rows
 
     def bake_png_rows(self, rgbe, input_downscale=1, cubemap_size=16, lambertian=True, ggx=True, ggx_samples=0,
-                      lod_bias=1.0):
-        """bake_rgbe, but every result is the (6*S, 4*S+1) uint8 PNG scanline stream of its strip."""
+                      lod_bias=1.0, _expose=None):
+        """bake_rgbe, but every result is the (6*S, 4*S+1) uint8 PNG scanline stream of its strip.
+        _expose: a dict that receives the output buffers ("lam", "ggx") before the call starts, so that a
+        progress callback can look at a cube the moment it is reported."""
         rgbe = np.ascontiguousarray(rgbe, dtype=np.uint8)
         w = rgbe.shape[1]
         assert rgbe.shape == (6 * w, w, 4), rgbe.shape
@@ -497,12 +499,14 @@ class Ibl:
         sizes = [w >> m for m in range(1, mips + 1)]
         total = sum(6 * s * (4 * s + 1) for s in sizes)
         gbuf = np.zeros(max(total, 1), np.uint8) if ggx else None
-        self._check(self.lib.ibl_bake_png_rows(rgbe.ctypes.data, w, input_downscale, cubemap_size, ggx_samples,
-                                               float(lod_bias), lam.ctypes.data if lambertian else None,
-                                               gbuf.ctypes.data if ggx else None))
         levels, off = [], 0
         for s in sizes:
             n = 6 * s * (4 * s + 1)
             levels.append(gbuf[off:off + n].reshape(6 * s, 4 * s + 1))
             off += n
+        if _expose is not None:
+            _expose["lam"], _expose["ggx"] = lam, levels
+        self._check(self.lib.ibl_bake_png_rows(rgbe.ctypes.data, w, input_downscale, cubemap_size, ggx_samples,
+                                               float(lod_bias), lam.ctypes.data if lambertian else None,
+                                               gbuf.ctypes.data if ggx else None))
         return lam, levels

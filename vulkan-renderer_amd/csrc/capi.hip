@@ -54,7 +54,7 @@ struct State {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t timed_calls = 0;
     bool timing = false, counting = false, timed_valid = false;
-    Buffer a, b, pn, partial, counts, stage_in, stage_out, units;
+    Buffer a, b, pn, partial, counts, stage_in, stage_out, units, png;
     void* static_scratch = nullptr; // this device's copy of the file-scope scratch array (ibl_lambertian_static_dev)
     uint64_t last_counts[7] = {0, 0, 0, 0, 0, 0, 0};   // patch tests, texel tests, accepted, wave-records, wave-patterns, exact blocks
     int counts_pending = 0;          // 1: a GGX call's counters wait on the device, 2: a Lambertian call's
@@ -65,6 +65,9 @@ struct State {
 constexpr int MAX_DEVICES = 64;
 State g_states[MAX_DEVICES];
 thread_local State* S = nullptr;
+// A worker thread of a rehearsed multi-device call (one GPU playing several at once) works on a
+// temporary state of its own -- own workspaces, own stream -- instead of its device's.
+thread_local State* S_stand_in = nullptr;
 ibl::Tuning g_tuning;
 bool g_tuning_read = false;
 
@@ -93,6 +96,7 @@ void release(Buffer& buf) {
 }
 
 int check_ready() {
+    if (S_stand_in) { S = S_stand_in; return IBL_OK; }
     int d = -1;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES || !g_states[d].ready) {
         (void)hipGetLastError();
@@ -139,16 +143,7 @@ void read_tuning_once() {
 constexpr size_t STATIC_SCRATCH_BYTES = (size_t)64 << 20;
 __device__ __align__(256) unsigned char g_static_scratch[STATIC_SCRATCH_BYTES];
 
-int init_device(int device) {
-    State& st = g_states[device];
-    if (st.ready) return IBL_OK;
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
-    void* scratch = nullptr;
-    HIP_TRY(hipGetSymbolAddress(&scratch, HIP_SYMBOL(g_static_scratch)));
+int create_events(State& st) {
     for (int k = 0; k < TIMING_RING; k++) {
         hipError_t e0 = hipEventCreate(&st.ring0[k]);
         hipError_t e1 = e0 == hipSuccess ? hipEventCreate(&st.ring1[k]) : e0;
@@ -164,10 +159,35 @@ int init_device(int device) {
     st.ev0 = st.ring0[0];
     st.ev1 = st.ring1[0];
     st.timed_calls = 0;
+    return IBL_OK;
+}
+
+int init_device(int device) {
+    State& st = g_states[device];
+    if (st.ready) return IBL_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(IBL_ENODEV, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+    void* scratch = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&scratch, HIP_SYMBOL(g_static_scratch)));
+    if (int rc = create_events(st)) return rc;
     st.static_scratch = scratch;
     st.device = device;
     st.ready = true;
     return IBL_OK;
+}
+
+void drop_state(State& st) {
+    release(st.a); release(st.b); release(st.pn); release(st.partial); release(st.counts);
+    release(st.stage_in); release(st.stage_out); release(st.units); release(st.png);
+    for (int k = 0; k < TIMING_RING; k++) {
+        if (st.ring0[k]) (void)hipEventDestroy(st.ring0[k]);
+        if (st.ring1[k]) (void)hipEventDestroy(st.ring1[k]);
+    }
+    if (st.stream) (void)hipStreamDestroy(st.stream);
+    st = State();
 }
 
 void shutdown_device(int device) {
@@ -175,13 +195,7 @@ void shutdown_device(int device) {
     if (!st.ready) return;
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
-    release(st.a); release(st.b); release(st.pn); release(st.partial); release(st.counts);
-    release(st.stage_in); release(st.stage_out); release(st.units);
-    for (int k = 0; k < TIMING_RING; k++) {
-        if (st.ring0[k]) (void)hipEventDestroy(st.ring0[k]);
-        if (st.ring1[k]) (void)hipEventDestroy(st.ring1[k]);
-    }
-    st = State();
+    drop_state(st);
 }
 
 // The device counters of the counting kernel variants, zeroed on the stream (null when counting is off).
@@ -317,6 +331,7 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "ggx_few")) g_tuning.ggx_few = (float)value;
     else if (!strcmp(name, "ggx_sums_mib")) g_tuning.ggx_sums_mib = value;
     else if (!strcmp(name, "bake_rehearse_shards")) g_tuning.bake_rehearse_shards = (int)value;
+    else if (!strcmp(name, "bake_rehearse_concurrent")) g_tuning.bake_rehearse_concurrent = (int)value;
     else return fail(IBL_EINVAL, "set_tuning: unknown knob %s", name);
     return IBL_OK;
 }
@@ -339,6 +354,7 @@ int ibl_get_tuning(const char* name, double* value) {
     else if (!strcmp(name, "ggx_few")) *value = g_tuning.ggx_few;
     else if (!strcmp(name, "ggx_sums_mib")) *value = g_tuning.ggx_sums_mib;
     else if (!strcmp(name, "bake_rehearse_shards")) *value = g_tuning.bake_rehearse_shards;
+    else if (!strcmp(name, "bake_rehearse_concurrent")) *value = g_tuning.bake_rehearse_concurrent;
     else if (!strcmp(name, "general_only")) *value = g_tuning.no_octets ? 1.0 : 0.0;
     else return fail(IBL_EINVAL, "get_tuning: unknown knob %s", name);
     return IBL_OK;
@@ -969,6 +985,7 @@ int ibl_mirror_reproject_dev(const float* d_src, uint32_t w, const float* camera
 // ---- host-buffer entry points ---------------------------------------------------
 
 namespace {
+extern "C++" {
 
 // Copies `bytes` from the host into the staging-in buffer.
 int stage_in(const void* host, size_t bytes) {
@@ -983,6 +1000,105 @@ int stage_out(void* host, size_t bytes) {
     return IBL_OK;
 }
 
+// ---- one call on every initialised device ------------------------------------------------
+// The reference's integrateLambertian / integrateGGX / generateGGXLUT are one call that uses every
+// core of the host (cube.cpp:95,240).  With several devices initialised (ibl_init_all) the
+// host-buffer entry points and the bakes do the same with the GPUs: one host thread per device, every
+// device works on shard i of n of the output and the shards meet in the caller's host buffer.
+// A one-GPU machine rehearses that code with the knob "bake_rehearse_shards" = n: the one device
+// plays n shards, in turn on its own state or -- "bake_rehearse_concurrent" = 1 -- at once, every
+// thread on a stand-in state of its own (own workspaces, own stream), which is the concurrent shape
+// of the real thing.
+
+struct Fan {
+    std::vector<int> devices;     // device of every shard
+    bool stand_ins = false;       // every shard works on a temporary state of its own
+    bool in_turn = false;         // shards run one after the other
+};
+
+// The shards a host-buffer call is split into: empty for the plain one-device call.
+Fan fan_plan() {
+    Fan f;
+    for (int d = 0; d < MAX_DEVICES; d++) if (g_states[d].ready) f.devices.push_back(d);
+    if (f.devices.size() > 1) return f;
+    const int rehearse = g_tuning.bake_rehearse_shards;
+    f.devices.clear();
+    if (rehearse > 1 && S) {
+        f.devices.assign((size_t)rehearse, S->device);
+        f.stand_ins = g_tuning.bake_rehearse_concurrent != 0;
+        f.in_turn = !f.stand_ins;
+    }
+    return f;
+}
+
+// Runs fn(shard, n_shards) for every shard of the plan, each on its own host thread with its device
+// current; returns the first failure (with the device named in the message).
+template <typename Fn>
+int fan_out(const Fan& fan, Fn fn) {
+    const uint32_t n = (uint32_t)fan.devices.size();
+    int current = -1;
+    (void)hipGetDevice(&current);
+    std::vector<int> rcs(n, IBL_OK);
+    std::vector<std::string> messages(n);
+    std::vector<State> stand_ins(fan.stand_ins ? n : 0);
+    std::vector<std::thread> threads;
+    for (uint32_t i = 0; i < n; i++) {
+        threads.emplace_back([&, i]() {
+            int rc = IBL_OK;
+            if (hipSetDevice(fan.devices[i]) != hipSuccess) rc = fail(IBL_EHIP, "hipSetDevice(%d) failed", fan.devices[i]);
+            if (!rc && fan.stand_ins) {
+                State& st = stand_ins[i];
+                st.device = fan.devices[i];
+                st.static_scratch = g_states[st.device].static_scratch;
+                if (hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking) != hipSuccess)
+                    rc = fail(IBL_EHIP, "hipStreamCreate failed");
+                if (!rc) rc = create_events(st);
+                if (!rc) { st.ready = true; S_stand_in = &st; }
+            }
+            if (!rc) rc = check_ready();
+            if (!rc) rc = fn(i, n);
+            if (S) (void)hipStreamSynchronize(S->stream);
+            rcs[i] = rc;
+            if (rc) messages[i] = g_err;
+            if (fan.stand_ins) {
+                S_stand_in = nullptr;
+                drop_state(stand_ins[i]);
+            }
+        });
+        if (fan.in_turn) threads.back().join();
+    }
+    for (std::thread& t : threads) if (t.joinable()) t.join();
+    if (current >= 0) (void)hipSetDevice(current);
+    S_stand_in = nullptr;
+    (void)check_ready();
+    for (uint32_t i = 0; i < n; i++)
+        if (rcs[i]) return fail(rcs[i], "device %d: %s", fan.devices[i], messages[i].c_str());
+    return IBL_OK;
+}
+
+// This shard's float4 texels of a cube on the device (full-size d_cube) into their places in the
+// caller's host cube.  Shards are disjoint, so the threads write different texels.
+int deliver_shard(const ibl::ShardMap& map, uint32_t shard, const float* d_cube, float* host_cube) {
+    const uint32_t per = ibl::shard_slots(map);
+    if (int rc = ensure(S->png, (size_t)per * 16)) return rc;
+    HIP_TRY(ibl::shard_pack_launch(map, shard, 16, d_cube, S->png.ptr, S->stream));
+    std::vector<float> packed((size_t)per * 4);
+    std::vector<uint32_t> slots(per);
+    HIP_TRY(hipMemcpyAsync(packed.data(), S->png.ptr, (size_t)per * 16, hipMemcpyDeviceToHost, S->stream));
+    ibl::shard_indices(map, shard, slots.data());          // host arithmetic, while the device works
+    HIP_TRY(hipStreamSynchronize(S->stream));
+    for (uint32_t k = 0; k < per; k++)
+        if (slots[k] != 0xffffffffu) memcpy(host_cube + (size_t)slots[k] * 4, packed.data() + (size_t)k * 4, 16);
+    return IBL_OK;
+}
+
+ibl::ShardMap range_map(uint32_t out_w, uint32_t n_shards) {
+    ibl::ShardMap map;
+    map.partition = ibl::SHARD_RANGE; map.out_w = out_w; map.tw = 1; map.n_shards = n_shards;
+    return map;
+}
+
+}  // extern "C++"
 }  // namespace
 
 int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_size, float* out) {
@@ -991,10 +1107,21 @@ int ibl_lambertian(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_
     if (int rc = check_cube(in_w, in_h, "lambertian input")) return rc;
     if (int rc = check_cube(out_size, out_size, "lambertian output")) return rc;
     const size_t in_bytes = (size_t)in_w * in_h * 6 * 16, out_bytes = (size_t)out_size * out_size * 6 * 16;
+    const Fan fan = fan_plan();
+    if (!fan.devices.empty())
+        return fan_out(fan, [&](uint32_t shard, uint32_t n) -> int {
+            ibl::ShardMap map;
+            if (int rc = shard_map(IBL_SHARD_LAMBERTIAN, in_w, out_size, 1, 1, n, &map)) return rc;
+            if (int rc = stage_in(env, in_bytes)) return rc;
+            if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+            if (int rc = ibl_lambertian_shard_dev((const float*)S->stage_in.ptr, in_w, in_h, out_size, shard, n,
+                                                  (float*)S->stage_out.ptr, S->stream)) return rc;
+            return deliver_shard(map, shard, (const float*)S->stage_out.ptr, out);
+        });
     if (int rc = stage_in(env, in_bytes)) return rc;
     if (int rc = ensure(S->stage_out, out_bytes)) return rc;
     if (int rc = ibl_lambertian_dev((const float*)S->stage_in.ptr, in_w, in_h, out_size, 0, out_size * out_size * 6,
-                                    (float*)S->stage_out.ptr, nullptr)) return rc;
+                                    (float*)S->stage_out.ptr, S->stream)) return rc;
     return stage_out(out, out_bytes);
 }
 
@@ -1005,10 +1132,24 @@ int ibl_ggx_level(const float* env, uint32_t in_w, uint32_t in_h, uint32_t out_w
     if (int rc = check_cube(in_w, in_h, "ggx input")) return rc;
     if (int rc = check_cube(out_w, out_h, "ggx output")) return rc;
     const size_t in_bytes = (size_t)in_w * in_h * 6 * 16, out_bytes = (size_t)out_w * out_h * 6 * 16;
+    const Fan fan = fan_plan();
+    if (!fan.devices.empty()) {
+        uint32_t patch = 0;
+        if (int rc = ggx_check(env, in_w, in_h, out_w, out_h, mip_level, mip_levels, out, &patch)) return rc;
+        return fan_out(fan, [&](uint32_t shard, uint32_t n) -> int {
+            ibl::ShardMap map;
+            if (int rc = shard_map(IBL_SHARD_GGX, in_w, out_w, mip_level, mip_levels, n, &map)) return rc;
+            if (int rc = stage_in(env, in_bytes)) return rc;
+            if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+            if (int rc = ibl_ggx_level_shard_dev((const float*)S->stage_in.ptr, in_w, in_h, out_w, out_h, mip_level,
+                                                 mip_levels, shard, n, (float*)S->stage_out.ptr, S->stream)) return rc;
+            return deliver_shard(map, shard, (const float*)S->stage_out.ptr, out);
+        });
+    }
     if (int rc = stage_in(env, in_bytes)) return rc;
     if (int rc = ensure(S->stage_out, out_bytes)) return rc;
     if (int rc = ibl_ggx_level_dev((const float*)S->stage_in.ptr, in_w, in_h, out_w, out_h, mip_level, mip_levels, 0,
-                                   out_w * out_h * 6, (float*)S->stage_out.ptr, nullptr)) return rc;
+                                   out_w * out_h * 6, (float*)S->stage_out.ptr, S->stream)) return rc;
     return stage_out(out, out_bytes);
 }
 
@@ -1019,13 +1160,26 @@ int ibl_ggx_level_sampled(const float* env, uint32_t in_w, uint32_t out_w, uint3
     if (int rc = check_cube(in_w, in_w, "ggx_sampled input")) return rc;
     if (int rc = check_cube(out_w, out_w, "ggx_sampled output")) return rc;
     const size_t in_bytes = (size_t)in_w * in_w * 6 * 16, out_bytes = (size_t)out_w * out_w * 6 * 16;
-    if (int rc = stage_in(env, in_bytes)) return rc;
-    if (int rc = ensure(S->a, (size_t)ibl_env_pyramid_texels(in_w) * 16)) return rc;
-    if (int rc = ensure(S->stage_out, out_bytes)) return rc;
-    if (int rc = ibl_env_pyramid_dev((const float*)S->stage_in.ptr, in_w, (float*)S->a.ptr, nullptr)) return rc;
-    if (int rc = ibl_ggx_level_sampled_dev((const float*)S->a.ptr, in_w, out_w, mip_level, mip_levels, n_samples, lod_bias,
-                                           0, out_w * out_w * 6, (float*)S->stage_out.ptr, nullptr)) return rc;
-    return stage_out(out, out_bytes);
+    const uint32_t n_out = out_w * out_w * 6;
+    const Fan fan = fan_plan();
+    // (sampled mode: shards are plain texel ranges, copied straight into their place)
+    auto part = [&](uint32_t shard, uint32_t n) -> int {
+        const uint32_t per = (n_out + n - 1) / n;
+        const uint32_t begin = shard * per < n_out ? shard * per : n_out;
+        const uint32_t count = per < n_out - begin ? per : n_out - begin;
+        if (int rc = stage_in(env, in_bytes)) return rc;
+        if (int rc = ensure(S->a, (size_t)ibl_env_pyramid_texels(in_w) * 16)) return rc;
+        if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+        if (int rc = ibl_env_pyramid_dev((const float*)S->stage_in.ptr, in_w, (float*)S->a.ptr, S->stream)) return rc;
+        if (int rc = ibl_ggx_level_sampled_dev((const float*)S->a.ptr, in_w, out_w, mip_level, mip_levels, n_samples,
+                                               lod_bias, begin, count, (float*)S->stage_out.ptr, S->stream)) return rc;
+        HIP_TRY(hipMemcpyAsync(out + (size_t)begin * 4, (const float*)S->stage_out.ptr + (size_t)begin * 4, (size_t)count * 16,
+                               hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        return IBL_OK;
+    };
+    if (!fan.devices.empty()) return fan_out(fan, part);
+    return part(0, 1);
 }
 
 int ibl_brdf_lut(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64_t seed, int jitter_mode,
@@ -1034,11 +1188,24 @@ int ibl_brdf_lut(uint32_t n_rough, uint32_t n_cos, uint32_t samples_sqrt, uint64
     if (!out_slope_bias) return fail(IBL_EINVAL, "brdf_lut: null pointer");
     if (n_rough == 0 || n_cos == 0 || (uint64_t)n_rough * n_cos > (1u << 26))
         return fail(IBL_EINVAL, "brdf_lut: table %ux%u out of range", n_rough, n_cos);
-    const size_t out_bytes = (size_t)n_rough * n_cos * 2 * sizeof(float);
-    if (int rc = ensure(S->stage_out, out_bytes)) return rc;
-    if (int rc = ibl_brdf_lut_dev(n_rough, n_cos, samples_sqrt, seed, jitter_mode, 0, n_rough * n_cos,
-                                  (float*)S->stage_out.ptr, nullptr)) return rc;
-    return stage_out(out_slope_bias, out_bytes);
+    const uint32_t n_cells = n_rough * n_cos;
+    const size_t out_bytes = (size_t)n_cells * 2 * sizeof(float);
+    // every cell is independent (cube.cpp:346-388): shards are ranges of cells
+    auto part = [&](uint32_t shard, uint32_t n) -> int {
+        const uint32_t per = (n_cells + n - 1) / n;
+        const uint32_t begin = shard * per < n_cells ? shard * per : n_cells;
+        const uint32_t count = per < n_cells - begin ? per : n_cells - begin;
+        if (int rc = ensure(S->stage_out, out_bytes)) return rc;
+        if (int rc = ibl_brdf_lut_dev(n_rough, n_cos, samples_sqrt, seed, jitter_mode, begin, count,
+                                      (float*)S->stage_out.ptr, S->stream)) return rc;
+        HIP_TRY(hipMemcpyAsync(out_slope_bias + (size_t)begin * 2, (const float*)S->stage_out.ptr + (size_t)begin * 2,
+                               (size_t)count * 2 * sizeof(float), hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        return IBL_OK;
+    };
+    const Fan fan = fan_plan();
+    if (!fan.devices.empty()) return fan_out(fan, part);
+    return part(0, 1);
 }
 
 int ibl_rgbe_decode(const uint8_t* rgbe, float* rgba, uint32_t n) {
@@ -1047,7 +1214,7 @@ int ibl_rgbe_decode(const uint8_t* rgbe, float* rgba, uint32_t n) {
     if (!rgbe || !rgba) return fail(IBL_EINVAL, "rgbe_decode: null pointer");
     if (int rc = stage_in(rgbe, (size_t)n * 4)) return rc;
     if (int rc = ensure(S->stage_out, (size_t)n * 16)) return rc;
-    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)S->stage_in.ptr, (float*)S->stage_out.ptr, n, nullptr)) return rc;
+    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)S->stage_in.ptr, (float*)S->stage_out.ptr, n, S->stream)) return rc;
     return stage_out(rgba, (size_t)n * 16);
 }
 
@@ -1057,7 +1224,7 @@ int ibl_rgbe_encode(const float* rgba, uint8_t* rgbe, uint32_t n) {
     if (!rgba || !rgbe) return fail(IBL_EINVAL, "rgbe_encode: null pointer");
     if (int rc = stage_in(rgba, (size_t)n * 16)) return rc;
     if (int rc = ensure(S->stage_out, (size_t)n * 4)) return rc;
-    if (int rc = ibl_rgbe_encode_dev((const float*)S->stage_in.ptr, (uint8_t*)S->stage_out.ptr, n, nullptr)) return rc;
+    if (int rc = ibl_rgbe_encode_dev((const float*)S->stage_in.ptr, (uint8_t*)S->stage_out.ptr, n, S->stream)) return rc;
     return stage_out(rgbe, (size_t)n * 4);
 }
 
@@ -1069,7 +1236,7 @@ int ibl_downscale(const float* env, uint32_t w, uint32_t h, uint32_t d, float* o
     const size_t in_bytes = (size_t)w * h * 6 * 16, out_bytes = (size_t)(w / d) * (h / d) * 6 * 16;
     if (int rc = stage_in(env, in_bytes)) return rc;
     if (int rc = ensure(S->stage_out, out_bytes)) return rc;
-    if (int rc = ibl_downscale_dev((const float*)S->stage_in.ptr, w, h, d, (float*)S->stage_out.ptr, nullptr)) return rc;
+    if (int rc = ibl_downscale_dev((const float*)S->stage_in.ptr, w, h, d, (float*)S->stage_out.ptr, S->stream)) return rc;
     return stage_out(out, out_bytes);
 }
 
@@ -1081,13 +1248,13 @@ int ibl_png_filter_rows(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t* r
     const size_t out_bytes = (size_t)ibl_png_rows_bytes(w, h);
     if (int rc = stage_in(rgba8, (size_t)w * h * 4)) return rc;
     if (int rc = ensure(S->stage_out, out_bytes)) return rc;
-    if (int rc = ibl_png_filter_rows_dev((const uint8_t*)S->stage_in.ptr, w, h, (uint8_t*)S->stage_out.ptr, nullptr)) return rc;
+    if (int rc = ibl_png_filter_rows_dev((const uint8_t*)S->stage_in.ptr, w, h, (uint8_t*)S->stage_out.ptr, S->stream)) return rc;
     return stage_out(rows, out_bytes);
 }
 
 namespace {
-int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size, uint32_t ggx_samples,
-         float lod_bias, bool png_rows, uint8_t* lambertian_out, uint8_t* ggx_out);
+extern "C++" int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size, uint32_t ggx_samples,
+                      float lod_bias, bool png_rows, uint8_t* lambertian_out, uint8_t* ggx_out);
 }
 
 int ibl_bake_rgbe(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size,
@@ -1106,15 +1273,15 @@ int ibl_bake_png_rows(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downsca
 }
 
 namespace {
+extern "C++" {
 
 ibl_progress_fn g_progress = nullptr;
 void* g_progress_user = nullptr;
 std::mutex g_progress_mutex;
 
 void report_done(int cube) {
-    if (!g_progress) return;
     std::lock_guard<std::mutex> lock(g_progress_mutex);
-    g_progress(cube, g_progress_user);
+    if (g_progress) g_progress(cube, g_progress_user);
 }
 
 struct BakeJob {
@@ -1141,94 +1308,130 @@ int bake_environment(const BakeJob& job, float** d_env, uint32_t* env_w) {
     float* d_full = (float*)(base + off_full);
     *d_env = d_full;
     *env_w = dw;
-    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)base, d_full, n_full, nullptr)) return rc;
+    if (int rc = ibl_rgbe_decode_dev((const uint8_t*)base, d_full, n_full, S->stream)) return rc;
     if (job.input_downscale > 1) {
         *d_env = (float*)(base + off_ds);
-        if (int rc = ibl_downscale_dev(d_full, w, w, job.input_downscale, *d_env, nullptr)) return rc;
+        if (int rc = ibl_downscale_dev(d_full, w, w, job.input_downscale, *d_env, S->stream)) return rc;
     }
     return IBL_OK;
 }
 
-// pixels: the RGBE texels of one finished cube (n of them, faces of edge `edge`); hands them to the
-// caller as they are or as PNG scanlines, and returns the number of bytes written to dst.
-int emit(const float* d_f, uint8_t* d_e, uint8_t* d_rows, uint32_t edge, bool png_rows, uint8_t* dst, size_t* written) {
-    const uint32_t n = edge * edge * 6;
-    if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n, nullptr)) return rc;
-    const uint8_t* src = d_e;
-    size_t bytes = (size_t)n * 4;
-    if (png_rows) {
-        if (int rc = ibl_png_filter_rows_dev(d_e, edge, edge * 6, d_rows, nullptr)) return rc;
-        src = d_rows;
-        bytes = (size_t)ibl_png_rows_bytes(edge, edge * 6);
+// The cubes of a bake in the order they are baked and reported: the Lambertian cube (report 0), then
+// the GGX levels 1 .. mips; where each one's bytes go in the caller's buffers.
+struct BakeCube {
+    bool lambertian = false;
+    uint32_t level = 0;           // GGX level (0 for the Lambertian cube): also the number reported
+    uint32_t edge = 0;
+    uint8_t* dst = nullptr;       // RGBE texels or PNG scanlines in the caller's buffer
+    size_t bytes = 0;
+};
+
+std::vector<BakeCube> bake_cubes(const BakeJob& job) {
+    std::vector<BakeCube> cubes;
+    auto size_of = [&](uint32_t edge) {
+        return job.png_rows ? (size_t)ibl_png_rows_bytes(edge, edge * 6) : (size_t)edge * edge * 6 * 4;
+    };
+    if (job.lambertian_out) {
+        BakeCube c;
+        c.lambertian = true; c.edge = job.cubemap_size; c.dst = job.lambertian_out; c.bytes = size_of(c.edge);
+        cubes.push_back(c);
     }
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S->stream));
-    HIP_TRY(hipStreamSynchronize(S->stream));
-    *written = bytes;
-    return IBL_OK;
+    size_t off = 0;
+    uint32_t mw = job.w / 2;
+    for (uint32_t m = 1; m <= job.mips; m++, mw /= 2) {
+        BakeCube c;
+        c.level = m; c.edge = mw; c.dst = job.ggx_out + off; c.bytes = size_of(mw);
+        off += c.bytes;
+        cubes.push_back(c);
+    }
+    return cubes;
 }
 
-// The whole bake on the current device.
+// The whole bake on the current device.  The cubes go through two sets of output buffers in turn: a
+// cube's kernels, its encoding and its copy to the host are queued, and only then is the cube before
+// it waited for and reported -- so whatever the progress callback does with a finished cube (bin/cube
+// deflates it and writes its file) happens while the device works on the next one.
 int bake_single(const BakeJob& job) {
-    const uint32_t w = job.w;
     float* d_env = nullptr;
     uint32_t dw = 0;
     if (int rc = bake_environment(job, &d_env, &dw)) return rc;
-    const uint32_t n_lamb = job.cubemap_size * job.cubemap_size * 6;
-    uint32_t n_max = job.lambertian_out ? n_lamb : 0;
-    if (job.mips) { uint32_t n1 = (w / 2) * (w / 2) * 6; if (n1 > n_max) n_max = n1; }
+    const std::vector<BakeCube> cubes = bake_cubes(job);
+    uint32_t n_max = 0;
+    for (const BakeCube& c : cubes) if (c.edge * c.edge * 6 > n_max) n_max = c.edge * c.edge * 6;
     if (n_max == 0) return IBL_OK;
-    // Staging-out block: [float cube of the largest output][its RGBE bytes][its PNG scanlines]
+    // Staging-out block, twice: [float cube of the largest output][its RGBE bytes][its PNG scanlines]
     const size_t off_bytes = (size_t)n_max * 16;
     const size_t off_rows = off_bytes + (size_t)n_max * 4;
-    if (int rc = ensure(S->stage_out, off_rows + (job.png_rows ? (size_t)n_max * 4 + (size_t)n_max : 0))) return rc;
-    float* d_f = (float*)S->stage_out.ptr;
-    uint8_t* d_e = (uint8_t*)S->stage_out.ptr + off_bytes;
-    uint8_t* d_rows = (uint8_t*)S->stage_out.ptr + off_rows;
-    size_t written = 0;
-    if (job.lambertian_out) {
-        if (int rc = ibl_lambertian_dev(d_env, dw, dw, job.cubemap_size, 0, n_lamb, d_f, nullptr)) return rc;
-        if (int rc = emit(d_f, d_e, d_rows, job.cubemap_size, job.png_rows, job.lambertian_out, &written)) return rc;
-        report_done(0);
-    }
+    const size_t set_bytes = (off_rows + (job.png_rows ? (size_t)n_max * 4 + (size_t)n_max : 0) + 255) & ~(size_t)255;
+    if (int rc = ensure(S->stage_out, 2 * set_bytes)) return rc;
     if (job.mips && job.ggx_samples) {      // sampled mode: one pyramid of the (downscaled) environment for all levels
         if (int rc = ensure(S->b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
-        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)S->b.ptr, nullptr)) return rc;
+        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)S->b.ptr, S->stream)) return rc;
     }
-    size_t out_off = 0;
-    uint32_t mw = w / 2;
-    for (uint32_t m = 1; m <= job.mips; m++, mw /= 2) {
-        const uint32_t n_m = mw * mw * 6;
-        if (job.ggx_samples) {
-            if (int rc = ibl_ggx_level_sampled_dev((const float*)S->b.ptr, dw, mw, m, job.mips, job.ggx_samples,
-                                                   job.lod_bias, 0, n_m, d_f, nullptr)) return rc;
-        } else if (int rc = ibl_ggx_level_dev(d_env, dw, dw, mw, mw, m, job.mips, 0, n_m, d_f, nullptr)) return rc;
-        if (int rc = emit(d_f, d_e, d_rows, mw, job.png_rows, job.ggx_out + out_off, &written)) return rc;
-        out_off += written;
-        report_done((int)m);
+    hipEvent_t copied[2] = {nullptr, nullptr};
+    HIP_TRY(hipEventCreateWithFlags(&copied[0], hipEventDisableTiming));
+    if (hipEventCreateWithFlags(&copied[1], hipEventDisableTiming) != hipSuccess) {
+        (void)hipEventDestroy(copied[0]);
+        return fail(IBL_EHIP, "hipEventCreate failed");
     }
-    return IBL_OK;
+    auto queue = [&](size_t ci) -> int {
+        const BakeCube& c = cubes[ci];
+        uint8_t* base = (uint8_t*)S->stage_out.ptr + (ci & 1) * set_bytes;
+        float* d_f = (float*)base;
+        uint8_t* d_e = base + off_bytes;
+        uint8_t* d_rows = base + off_rows;
+        const uint32_t n = c.edge * c.edge * 6;
+        if (c.lambertian) {
+            if (int rc = ibl_lambertian_dev(d_env, dw, dw, c.edge, 0, n, d_f, S->stream)) return rc;
+        } else if (job.ggx_samples) {
+            if (int rc = ibl_ggx_level_sampled_dev((const float*)S->b.ptr, dw, c.edge, c.level, job.mips, job.ggx_samples,
+                                                   job.lod_bias, 0, n, d_f, S->stream)) return rc;
+        } else if (int rc = ibl_ggx_level_dev(d_env, dw, dw, c.edge, c.edge, c.level, job.mips, 0, n, d_f, S->stream)) return rc;
+        if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n, S->stream)) return rc;
+        const uint8_t* src = d_e;
+        if (job.png_rows) {
+            if (int rc = ibl_png_filter_rows_dev(d_e, c.edge, c.edge * 6, d_rows, S->stream)) return rc;
+            src = d_rows;
+        }
+        HIP_TRY(hipMemcpyAsync(c.dst, src, c.bytes, hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipEventRecord(copied[ci & 1], S->stream));
+        return IBL_OK;
+    };
+    int rc = IBL_OK;
+    for (size_t ci = 0; ci <= cubes.size() && !rc; ci++) {
+        if (ci < cubes.size()) rc = queue(ci);
+        if (!rc && ci > 0) {
+            if (hipEventSynchronize(copied[(ci - 1) & 1]) != hipSuccess) rc = fail(IBL_EHIP, "hipEventSynchronize failed");
+            else report_done((int)cubes[ci - 1].level);
+        }
+    }
+    (void)hipStreamSynchronize(S->stream);
+    (void)hipEventDestroy(copied[0]);
+    (void)hipEventDestroy(copied[1]);
+    return rc;
 }
 
 // ---- the bake on several devices of one process ----------------------------------------
-// One host thread per initialised device.  Every device decodes the strip for itself, computes
-// its shard of every cube (the partition of the *_shard_dev entry points), encodes it, packs its
-// texels (ibl_shard_pack_dev) and copies them to the host, where the thread scatters them into
-// the cube's RGBE bytes: shards are disjoint, so the threads write different words.  A texel
-// does not depend on the number of devices, so the bytes are those of the one-device bake.
+// One host thread per device (fan_out).  Every device decodes the strip for itself, computes its shard
+// of every cube (the partition of the *_shard_dev entry points), encodes it, packs its texels
+// (ibl_shard_pack_dev) and copies them to the host, where the thread scatters them into the cube's
+// RGBE bytes: shards are disjoint, so the threads write different words.  A texel does not depend on
+// the number of devices, so the bytes are those of the one-device bake.  The thread that delivers the
+// last shard of a cube finishes it -- in PNG mode it filters the assembled texels on its own device --
+// and reports it, so finished cubes reach the caller while the other cubes are still being baked.
 
 struct SharedCube {
-    uint32_t edge = 0;
-    uint8_t* bytes = nullptr;              // the cube's RGBE texels on the host (caller's buffer or temporary)
-    std::atomic<int> waiting{0};           // devices that have not delivered their shard yet
+    BakeCube cube;
+    uint8_t* texels = nullptr;             // the cube's RGBE texels on the host (caller's buffer, or temporary in PNG mode)
+    std::atomic<int> waiting{0};           // shards that have not been delivered yet
 };
 
 int bake_shard(const BakeJob& job, uint32_t shard, uint32_t n_shards, std::vector<SharedCube>& cubes) {
-    const uint32_t w = job.w;
     float* d_env = nullptr;
     uint32_t dw = 0;
     if (int rc = bake_environment(job, &d_env, &dw)) return rc;
     uint32_t n_max = 0;
-    for (const SharedCube& c : cubes) if (c.edge * c.edge * 6 > n_max) n_max = c.edge * c.edge * 6;
+    for (const SharedCube& c : cubes) if (c.cube.edge * c.cube.edge * 6 > n_max) n_max = c.cube.edge * c.cube.edge * 6;
     if (n_max == 0) return IBL_OK;
     // Staging-out block: [float cube][its RGBE bytes][this shard's packed RGBE texels]
     const size_t off_bytes = (size_t)n_max * 16;
@@ -1239,30 +1442,28 @@ int bake_shard(const BakeJob& job, uint32_t shard, uint32_t n_shards, std::vecto
     uint8_t* d_packed = (uint8_t*)S->stage_out.ptr + off_packed;
     if (job.mips && job.ggx_samples) {
         if (int rc = ensure(S->b, (size_t)ibl_env_pyramid_texels(dw) * 16)) return rc;
-        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)S->b.ptr, nullptr)) return rc;
+        if (int rc = ibl_env_pyramid_dev(d_env, dw, (float*)S->b.ptr, S->stream)) return rc;
     }
     std::vector<uint32_t> packed, slots;
-    for (size_t ci = 0; ci < cubes.size(); ci++) {
-        SharedCube& cube = cubes[ci];
-        const bool lambertian = job.lambertian_out && ci == 0;
-        const uint32_t m = (uint32_t)ci + (job.lambertian_out ? 0u : 1u);     // GGX level of this cube
-        const uint32_t edge = cube.edge, n_out = edge * edge * 6;
+    for (SharedCube& shared : cubes) {
+        const BakeCube& c = shared.cube;
+        const uint32_t edge = c.edge, n_out = edge * edge * 6, m = c.level;
         ibl::ShardMap map;
-        if (lambertian) {
+        if (c.lambertian) {
             if (int rc = shard_map(IBL_SHARD_LAMBERTIAN, dw, edge, 1, 1, n_shards, &map)) return rc;
-            if (int rc = ibl_lambertian_shard_dev(d_env, dw, dw, edge, shard, n_shards, d_f, nullptr)) return rc;
+            if (int rc = ibl_lambertian_shard_dev(d_env, dw, dw, edge, shard, n_shards, d_f, S->stream)) return rc;
         } else if (job.ggx_samples) {       // sampled mode: plain texel ranges
-            map.partition = ibl::SHARD_RANGE; map.out_w = edge; map.tw = 1; map.n_shards = n_shards;
+            map = range_map(edge, n_shards);
             const uint32_t per = (n_out + n_shards - 1) / n_shards;
             const uint32_t begin = shard * per < n_out ? shard * per : n_out;
             const uint32_t count = per < n_out - begin ? per : n_out - begin;
             if (int rc = ibl_ggx_level_sampled_dev((const float*)S->b.ptr, dw, edge, m, job.mips, job.ggx_samples,
-                                                   job.lod_bias, begin, count, d_f, nullptr)) return rc;
+                                                   job.lod_bias, begin, count, d_f, S->stream)) return rc;
         } else {
             if (int rc = shard_map(IBL_SHARD_GGX, dw, edge, m, job.mips, n_shards, &map)) return rc;
-            if (int rc = ibl_ggx_level_shard_dev(d_env, dw, dw, edge, edge, m, job.mips, shard, n_shards, d_f, nullptr)) return rc;
+            if (int rc = ibl_ggx_level_shard_dev(d_env, dw, dw, edge, edge, m, job.mips, shard, n_shards, d_f, S->stream)) return rc;
         }
-        if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n_out, nullptr)) return rc;
+        if (int rc = ibl_rgbe_encode_dev(d_f, d_e, n_out, S->stream)) return rc;
         const uint32_t per = ibl::shard_slots(map);
         HIP_TRY(ibl::shard_pack_launch(map, shard, 4, d_e, d_packed, S->stream));
         packed.resize(per);
@@ -1270,72 +1471,41 @@ int bake_shard(const BakeJob& job, uint32_t shard, uint32_t n_shards, std::vecto
         HIP_TRY(hipMemcpyAsync(packed.data(), d_packed, (size_t)per * 4, hipMemcpyDeviceToHost, S->stream));
         ibl::shard_indices(map, shard, slots.data());          // host arithmetic, while the device works
         HIP_TRY(hipStreamSynchronize(S->stream));
-        uint32_t* dst = (uint32_t*)cube.bytes;
+        uint32_t* dst = (uint32_t*)shared.texels;
         for (uint32_t k = 0; k < per; k++)
             if (slots[k] != 0xffffffffu) dst[slots[k]] = packed[k];
-        if (cube.waiting.fetch_sub(1) == 1 && !job.png_rows) report_done(lambertian ? 0 : (int)m);
+        if (shared.waiting.fetch_sub(1) != 1) continue;
+        // the last shard of this cube: every texel is in place (the counter orders the other threads' stores)
+        if (job.png_rows) {
+            const size_t in_bytes = (size_t)n_out * 4;
+            const size_t in_pad = (in_bytes + 255) & ~(size_t)255;
+            if (int rc = ensure(S->png, in_pad + c.bytes)) return rc;
+            uint8_t* d_in = (uint8_t*)S->png.ptr;
+            HIP_TRY(hipMemcpyAsync(d_in, shared.texels, in_bytes, hipMemcpyHostToDevice, S->stream));
+            if (int rc = ibl_png_filter_rows_dev(d_in, edge, edge * 6, d_in + in_pad, S->stream)) return rc;
+            HIP_TRY(hipMemcpyAsync(c.dst, d_in + in_pad, c.bytes, hipMemcpyDeviceToHost, S->stream));
+            HIP_TRY(hipStreamSynchronize(S->stream));
+        }
+        report_done((int)m);
     }
-    (void)w;
     return IBL_OK;
 }
 
-// rehearse > 1: one device plays that many shards one after the other (the way to run the
-// shard, pack and scatter code on a machine with one GPU; the tests use it).
-int bake_multi(const BakeJob& job, std::vector<int> devices, uint32_t rehearse) {
-    if (rehearse > 1) devices.assign(rehearse, devices[0]);
-    const uint32_t n = (uint32_t)devices.size();
-    std::vector<SharedCube> cubes((job.lambertian_out ? 1 : 0) + job.mips);
+int bake_multi(const BakeJob& job, const Fan& fan) {
+    const uint32_t n = (uint32_t)fan.devices.size();
+    const std::vector<BakeCube> list = bake_cubes(job);
+    std::vector<SharedCube> cubes(list.size());
     std::vector<std::vector<uint8_t>> temp(cubes.size());          // PNG mode: the RGBE texels wait here for the filter
-    {
-        size_t ci = 0, off = 0;
-        if (job.lambertian_out) { cubes[ci].edge = job.cubemap_size; cubes[ci].bytes = job.lambertian_out; ci++; }
-        uint32_t mw = job.w / 2;
-        for (uint32_t m = 1; m <= job.mips; m++, mw /= 2, ci++) {
-            cubes[ci].edge = mw;
-            cubes[ci].bytes = job.ggx_out + off;
-            off += (size_t)mw * mw * 6 * 4;
-        }
-        for (size_t i = 0; i < cubes.size(); i++) {
-            cubes[i].waiting = (int)n;
-            if (job.png_rows) {
-                temp[i].assign((size_t)cubes[i].edge * cubes[i].edge * 6 * 4, 0);
-                cubes[i].bytes = temp[i].data();
-            }
+    for (size_t i = 0; i < cubes.size(); i++) {
+        cubes[i].cube = list[i];
+        cubes[i].waiting = (int)n;
+        cubes[i].texels = list[i].dst;
+        if (job.png_rows) {
+            temp[i].assign((size_t)list[i].edge * list[i].edge * 6 * 4, 0);
+            cubes[i].texels = temp[i].data();
         }
     }
-    std::vector<int> rcs(n, IBL_OK);
-    std::vector<std::string> messages(n);
-    std::vector<std::thread> threads;
-    for (uint32_t i = 0; i < n; i++) {
-        threads.emplace_back([&, i]() {
-            int rc = IBL_OK;
-            if (hipSetDevice(devices[i]) != hipSuccess) rc = fail(IBL_EHIP, "hipSetDevice(%d) failed", devices[i]);
-            if (!rc) rc = check_ready();
-            if (!rc) rc = bake_shard(job, i, n, cubes);
-            if (rc && S) (void)hipStreamSynchronize(S->stream);
-            rcs[i] = rc;
-            if (rc) messages[i] = g_err;
-        });
-        if (rehearse > 1) threads.back().join();       // one device: one shard at a time
-    }
-    for (std::thread& t : threads) if (t.joinable()) t.join();
-    for (uint32_t i = 0; i < n; i++)
-        if (rcs[i]) return fail(rcs[i], "device %d: %s", devices[i], messages[i].c_str());
-    if (!job.png_rows) return IBL_OK;
-    // PNG mode: the first device filters every assembled cube
-    HIP_TRY(hipSetDevice(devices[0]));
-    if (int rc = check_ready()) return rc;
-    size_t lam_off = 0, ggx_off = 0;
-    for (size_t ci = 0; ci < cubes.size(); ci++) {
-        const bool lambertian = job.lambertian_out && ci == 0;
-        const uint32_t edge = cubes[ci].edge;
-        uint8_t* dst = lambertian ? job.lambertian_out + lam_off : job.ggx_out + ggx_off;
-        if (int rc = ibl_png_filter_rows(cubes[ci].bytes, edge, edge * 6, dst)) return rc;
-        const size_t bytes = (size_t)ibl_png_rows_bytes(edge, edge * 6);
-        if (lambertian) lam_off += bytes; else ggx_off += bytes;
-        report_done(lambertian ? 0 : (int)(ci + (job.lambertian_out ? 0 : 1)));
-    }
-    return IBL_OK;
+    return fan_out(fan, [&](uint32_t shard, uint32_t n_shards) { return bake_shard(job, shard, n_shards, cubes); });
 }
 
 int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t cubemap_size, uint32_t ggx_samples,
@@ -1356,23 +1526,13 @@ int bake(const uint8_t* rgbe_in, uint32_t w, uint32_t input_downscale, uint32_t 
     job.mips = ggx_out ? ibl_ggx_mip_levels(w, w, cubemap_size) : 0;
     if (job.mips && w / input_downscale < 16)
         return fail(IBL_EINVAL, "ggx: input faces must be at least 16x16 (patch size would be 0), got %u", w / input_downscale);
-    std::vector<int> devices;
-    for (int d = 0; d < MAX_DEVICES; d++) if (g_states[d].ready) devices.push_back(d);
-    int current = -1;
-    (void)hipGetDevice(&current);
-    int rc;
-    if (devices.size() > 1 || g_tuning.bake_rehearse_shards > 1) {
-        if (devices.size() > 1) rc = bake_multi(job, devices, 0);
-        else rc = bake_multi(job, std::vector<int>(1, S->device), (uint32_t)g_tuning.bake_rehearse_shards);
-        if (current >= 0) (void)hipSetDevice(current);
-        (void)check_ready();
-    } else {
-        rc = bake_single(job);
-    }
+    const Fan fan = fan_plan();
+    int rc = fan.devices.empty() ? bake_single(job) : bake_multi(job, fan);
     // the copy from the caller's strip may still be queued when a later step has failed
     if (rc && S) (void)hipStreamSynchronize(S->stream);
     return rc;
 }
+}  // extern "C++"
 }  // namespace
 
 int ibl_set_progress(ibl_progress_fn fn, void* user) {

@@ -19,7 +19,8 @@ struct Tuning {
     int lamb_oct_affine = -1;      // octet Lambertian kernel: 1 / 0 force / forbid dealing slots to the XCDs (-1: automatic)
     double ggx_waves = 0.0;        // octet GGX kernel: waves per level to aim for (0: automatic)
     int ggx_xcd_slices = -1;       // octet GGX kernel: 1 / 0 force / forbid dealing runs to the XCDs (-1: automatic)
-    int bake_rehearse_shards = 0;  // ibl_bake_*: > 1 makes one device play that many shards in turn (tests)
+    int bake_rehearse_shards = 0;  // host-buffer calls and bakes: > 1 makes one device play that many shards in turn (tests)
+    int bake_rehearse_concurrent = 0; // ... 1: all at once, each on a stand-in state with its own workspaces and stream
     float ggx_core = 2.0f;         // multiple of alpha^2 below which the reference's own denominator is repeated
     int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)

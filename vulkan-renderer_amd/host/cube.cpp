@@ -157,7 +157,7 @@ void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) 
     ibl_set_progress(nullptr, nullptr);
     check(rc);
     if (!outs.error.empty()) PANIC(outs.error);
-    clock.lap("bake on the GPU, deflate and write the PNGs");
+    clock.lap("bake on the GPU with deflate and PNG writes of finished cubes beside it");
 }
 
 // Every environment of a scene, in the loader's numbering.
@@ -212,7 +212,7 @@ int run(int argc, char** argv) {
             opt.ggx_lod_bias = std::strtof(s.c_str(), &end);
             if (end == s.c_str() || *end != '\0') PANIC("invalid argument to --ggx-lod-bias");
         } else if (arg == "--generate-ggx-lut") {
-            check(ibl_init(0));
+            open_gpus();                 // the table's cells are split over every GPU, like the cubes
             generate_ggx_lut();
             return 0;
         } else if (arg == "--scene") {
