@@ -44,8 +44,9 @@
 //                flight while one is evaluated: no LDS, no barrier.  FP32 sums over 128 records
 //                (blue: the even and the odd records apart), FP64 over the slice, stored as FP32
 //                slice sums.
-//   ls_reduce / ls_final   runs of 8 slices, then all runs, in FP64; inverse transform, the odd
-//                half added, scaled, cancellation measured, stored where the range asks.
+//   ls_reduce / ls_final   runs of 8 slices, then all runs (8 interleaved parts, then those), in FP64;
+//                inverse transform, the odd half added, scaled, cancellation measured, stored where
+//                the range asks.
 #include "ibl_device.h"
 #include "ibl_kernels.h"
 
@@ -76,6 +77,10 @@ __global__ __launch_bounds__(256) void ls_prep(const float4* __restrict__ env, u
     double m[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) m[q] = 0.0;
+    float g[3] = {0.0f, 0.0f, 0.0f};
+    float e[LS_SUMS];
+#pragma unroll
+    for (int q = 0; q < LS_SUMS; q++) e[q] = 0.0f;        // (past the end: the zero record that pads an odd count)
     if (k < n_oct) {
         const uint32_t hw = w / 2;
         const uint32_t axis = k / (hw * hw);
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void ls_prep(const float4* __restrict__ env, u
         F3 d = ref_normal_from(c.face, c.x, c.y, w, w);       // all components > 0
         float l2 = ref_dot(d, d);
         float inv = 1.0f / (l2 * l2);                         // cube.cpp:116-117
-        const float g[3] = { d.x * inv, d.y * inv, d.z * inv };
+        g[0] = d.x * inv; g[1] = d.y * inv; g[2] = d.z * inv;
         double L[8][3];
 #pragma unroll
         for (uint32_t s = 0; s < 8; s++) {
@@ -93,7 +98,6 @@ __global__ __launch_bounds__(256) void ls_prep(const float4* __restrict__ env, u
             float4 v = env[(t.face * w + t.y) * w + t.x];     // cube.cpp:104 row stride (square faces)
             L[s][0] = v.x; L[s][1] = v.y; L[s][2] = v.z;
         }
-        float e[LS_SUMS];
         const uint32_t ks[4] = { 0u, 3u, 5u, 6u };
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -104,24 +108,6 @@ __global__ __launch_bounds__(256) void ls_prep(const float4* __restrict__ env, u
                 for (uint32_t s = 0; s < 8; s++) v += ls_sign(ks[q], s) * L[s][ch];
                 e[q * 3 + ch] = (float)v;
             }
-        // Two records to a 128-byte block, laid out for packed instructions on the pair:
-        //   0-5    g.x of both, g.y of both, g.z of both        6-7  unused
-        //   8+6q   (red, green) of coefficient q of the first record, the same of the second,
-        //          blue of both                                  (q = 0..3)
-        float* blk = (float*)(rec + (size_t)(k >> 1) * (2 * LS_REC));
-        const uint32_t h = k & 1u;
-        blk[h] = g[0]; blk[2 + h] = g[1]; blk[4 + h] = g[2]; blk[6 + h] = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            blk[8 + 6 * q + 2 * h] = e[3 * q];
-            blk[8 + 6 * q + 2 * h + 1] = e[3 * q + 1];
-            blk[8 + 6 * q + 4 + h] = e[3 * q + 2];
-        }
-        if (k + 1 == n_oct && h == 0u) {         // an odd count: the block's second record is all zero
-            blk[1] = 0.0f; blk[3] = 0.0f; blk[5] = 0.0f; blk[7] = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; q++) { blk[8 + 6 * q + 2] = 0.0f; blk[8 + 6 * q + 3] = 0.0f; blk[8 + 6 * q + 5] = 0.0f; }
-        }
         // first moment: member s points to (+-gx, +-gy, +-gz), minus where its bit is set
 #pragma unroll
         for (int ax = 0; ax < 3; ax++)
@@ -132,6 +118,39 @@ __global__ __launch_bounds__(256) void ls_prep(const float4* __restrict__ env, u
                 for (uint32_t s = 0; s < 8; s++) v += ls_sign(1u << ax, s) * L[s][ch];
                 m[ax * 3 + ch] = (double)g[ax] * v;
             }
+    }
+    // Two records to a 128-byte block, laid out for packed instructions on the pair:
+    //   0-5    g.x of both, g.y of both, g.z of both        6-7  unused (0)
+    //   8+6q   (red, green) of coefficient q of the first record, the same of the second,
+    //          blue of both                                  (q = 0..3)
+    // The two threads of a block swap what the other one stores and each writes one 64-byte half
+    // with four 16-byte stores (as 16 scattered 4-byte stores per thread this kernel took 43 us for a
+    // 1024 x 1024 face, most of what an eighth of a cube spends outside ls_pairs).
+    {
+        const uint32_t h = k & 1u;
+        float mine[16], other[16], blk[32];
+        mine[0] = g[0]; mine[1] = g[1]; mine[2] = g[2]; mine[3] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < LS_SUMS; q++) mine[4 + q] = e[q];
+#pragma unroll
+        for (int q = 0; q < 16; q++) other[q] = __shfl_xor(mine[q], 1);
+        const float* r0 = h ? other : mine;        // the block's first and second record
+        const float* r1 = h ? mine : other;
+        blk[0] = r0[0]; blk[1] = r1[0]; blk[2] = r0[1]; blk[3] = r1[1]; blk[4] = r0[2]; blk[5] = r1[2];
+        blk[6] = 0.0f; blk[7] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            blk[8 + 6 * q] = r0[4 + 3 * q]; blk[8 + 6 * q + 1] = r0[5 + 3 * q];
+            blk[8 + 6 * q + 2] = r1[4 + 3 * q]; blk[8 + 6 * q + 3] = r1[5 + 3 * q];
+            blk[8 + 6 * q + 4] = r0[6 + 3 * q]; blk[8 + 6 * q + 5] = r1[6 + 3 * q];
+        }
+        if ((k & ~1u) < n_oct) {
+            float4* dst = rec + (size_t)(k >> 1) * (2 * LS_REC) + 4u * h;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                dst[q] = h ? make_float4(blk[16 + 4 * q], blk[17 + 4 * q], blk[18 + 4 * q], blk[19 + 4 * q])
+                           : make_float4(blk[4 * q], blk[4 * q + 1], blk[4 * q + 2], blk[4 * q + 3]);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 9; q++) s_m[q][tid] = m[q];
@@ -146,6 +165,9 @@ __global__ __launch_bounds__(256) void ls_prep(const float4* __restrict__ env, u
     if (tid < 9) moment_parts[(size_t)blockIdx.x * 9 + tid] = s_m[tid][0];
 }
 
+// The workgroups' shares of the first moment in a fixed order.  (Folded into ls_prep -- the last
+// workgroup to finish adds them -- this cost 0.56 ms instead of saving 7 us: the release fence every
+// workgroup then needs writes back its XCD's whole L2, which is full of freshly written records.)
 __global__ __launch_bounds__(256) void ls_moment(const double* __restrict__ parts, uint32_t n_parts, double* __restrict__ moment) {
     __shared__ double s_m[9][256];
     const uint32_t tid = threadIdx.x;
@@ -365,44 +387,58 @@ __global__ __launch_bounds__(256) void ls_reduce(const float* __restrict__ parti
     *(double2*)(out + 2) = make_double2(c, d);
 }
 
-// One thread per output octet: the runs in order, the inverse transform, the odd half, the scale;
-// the 8 member texels that lie in the requested range are stored.  A wave here covers the same 64
-// octets as a wave of ls_pairs and leaves on the same condition.  flags[lo] is set where some
-// texel of the octet is the difference of much larger halves; flags[oct_local + ob]: somewhere in
-// the block; flags[oct_local + out_blocks]: anywhere.
-__global__ __launch_bounds__(256) void ls_final(const double* __restrict__ runs, uint32_t n_runs,
-                                                 const double* __restrict__ moment, uint32_t out_size,
-                                                 const uint32_t* __restrict__ block_list, uint32_t oct_begin,
-                                                 uint32_t oct_end, uint32_t out_blocks, uint32_t out_begin,
-                                                 uint32_t out_count, double scale, double limit,
-                                                 uint32_t* __restrict__ flags, unsigned long long* __restrict__ counts,
-                                                 float4* __restrict__ out) {
-    const uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x;
+// The runs of an output octet added up, the inverse transform, the odd half, the scale; the 8 member
+// texels that lie in the requested range are stored.  One workgroup of 8 waves per 64 output octets
+// (the same 64 as a wave of ls_pairs, and it leaves on the same condition): wave p adds the runs
+// p, p + 8, ... in order, then the first wave adds the 8 parts in order and finishes the octets (one
+// thread per octet adding all runs left this kernel with 48 workgroups for a whole 128 x 128 cube and
+// 30 us).  flags[lo] is set where some texel of the octet is the difference of much larger halves;
+// flags[oct_local + ob]: somewhere in its 256-octet block; flags[oct_local + out_blocks]: anywhere.
+constexpr int LS_FINAL_PARTS = 8;
+__global__ __launch_bounds__(64 * LS_FINAL_PARTS) void ls_final(
+    const double* __restrict__ runs, uint32_t n_runs, const double* __restrict__ moment, uint32_t out_size,
+    const uint32_t* __restrict__ block_list, uint32_t oct_begin, uint32_t oct_end, uint32_t out_blocks,
+    uint32_t out_begin, uint32_t out_count, double scale, double limit, uint32_t* __restrict__ flags,
+    unsigned long long* __restrict__ counts, float4* __restrict__ out) {
+    __shared__ double s_e[LS_FINAL_PARTS - 1][LS_SUMS][64];
+    const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6;
+    const uint32_t lo = blockIdx.x * 64u + lane;
     const uint32_t oct_local = out_blocks * LS_THREADS;
-    if (lo >= oct_local) return;
     const uint32_t ob = lo / LS_THREADS;
-    const uint32_t oo = (block_list ? block_list[ob] * LS_THREADS : oct_begin + ob * LS_THREADS) + lo % LS_THREADS;
-    if (oo >= oct_end) return;
+    const uint32_t oo_raw = (block_list ? block_list[ob] * LS_THREADS : oct_begin + ob * LS_THREADS) + lo % LS_THREADS;
+    const bool valid = oo_raw < oct_end;
+    const uint32_t oo = valid ? oo_raw : oct_end - 1;
     const uint32_t hw = out_size / 2;
     uint32_t axis, oj, oi;
     octet_decode(oo, hw, ls_tile_edge(hw), axis, oj, oi);
     {
         bool wanted = false;
+        if (valid) {
 #pragma unroll
-        for (uint32_t s = 0; s < 8; s++) {
-            Texel t = octet_member(axis, oj, oi, s, out_size, out_size);
-            const uint32_t o = (t.face * out_size + t.y) * out_size + t.x;
-            wanted = wanted || (o - out_begin < out_count);
+            for (uint32_t s = 0; s < 8; s++) {
+                Texel t = octet_member(axis, oj, oi, s, out_size, out_size);
+                const uint32_t o = (t.face * out_size + t.y) * out_size + t.x;
+                wanted = wanted || (o - out_begin < out_count);
+            }
         }
-        if (!__any(wanted)) return;          // ls_pairs stored nothing for this group
+        if (!__any(wanted)) return;          // ls_pairs stored nothing for these 64 (the same in every wave)
     }
     double e[LS_SUMS];
 #pragma unroll
     for (int q = 0; q < LS_SUMS; q++) e[q] = 0.0;
-    for (uint32_t b = 0; b < n_runs; b++) {
+    for (uint32_t b = part; b < n_runs; b += LS_FINAL_PARTS) {
 #pragma unroll
         for (int q = 0; q < LS_SUMS; q++) e[q] += runs[((size_t)b * LS_SUMS + q) * oct_local + lo];
     }
+    if (part > 0) {
+#pragma unroll
+        for (int q = 0; q < LS_SUMS; q++) s_e[part - 1][q][lane] = e[q];
+    }
+    __syncthreads();
+    if (part > 0 || !valid) return;
+    for (int p = 0; p < LS_FINAL_PARTS - 1; p++)
+#pragma unroll
+        for (int q = 0; q < LS_SUMS; q++) e[q] += s_e[p][q][lane];
     Texel c = octet_member(axis, oj, oi, 0, out_size, out_size);
     const F3 n = ref_normalize(ref_normal_from(c.face, c.x, c.y, out_size, out_size));
     const double nn[3] = { (double)n.x, (double)n.y, (double)n.z };
@@ -473,9 +509,9 @@ hipError_t lambertian_split_launch(const LambertianOctPlan& pl, const float* d_e
     if (ev1) (void)hipEventRecord(ev1, stream);
     ls_reduce<<<dim3((oct_local / 4 + 255) / 256, LS_SUMS, pl.n_runs), 256, 0, stream>>>(d_slices, pl.n_slices, oct_local, d_runs);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);      // cube.cpp:126
-    ls_final<<<(oct_local + 255) / 256, 256, 0, stream>>>(d_runs, pl.n_runs, d_moment, out_size, d_block_list, oct_begin, oct_end,
-                                                         pl.out_blocks, out_begin, out_count, scale,
-                                                         (double)tuning().lamb_split_limit, d_flags, d_counts, (float4*)d_out);
+    ls_final<<<oct_local / 64, 64 * LS_FINAL_PARTS, 0, stream>>>(d_runs, pl.n_runs, d_moment, out_size, d_block_list, oct_begin, oct_end,
+                                                pl.out_blocks, out_begin, out_count, scale,
+                                                (double)tuning().lamb_split_limit, d_flags, d_counts, (float4*)d_out);
     return hipGetLastError();
 }
 
