@@ -349,7 +349,9 @@ int ibl_set_tuning(const char* name, double value);
 int ibl_get_tuning(const char* name, double* value);
 
 /* When enabled, every *_dev call brackets its dominant kernel with HIP events on
- * the stream it was launched on. */
+ * the stream it was launched on.  A Lambertian call on the mirror-octet kernels has two: the
+ * split-form pair kernel and, behind it, the exact-weights pair kernel for the octets the first
+ * marked; ibl_last_kernel_ms / ibl_kernel_ms_back give the sum of the two. */
 int ibl_set_timing(int enabled);
 /* Waits for the last bracketed kernel and returns its duration in ms. */
 int ibl_last_kernel_ms(float* ms);

@@ -89,6 +89,21 @@ def test_png_io_rejects_garbage(tmp_path):
     p.write_bytes(b"not a png at all")
     r = _run(ROUNDTRIP, str(p), str(tmp_path / "y.png"))
     assert r.returncode == 1 and "not a PNG" in r.stderr
+    # a crafted header: 60000 x 60000 texels of 16-bit RGBA would wrap the reader's size arithmetic
+    import struct
+    import zlib
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data))
+    big = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 60000, 60000, 16, 6, 0, 0, 0))
+           + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""))
+    p.write_bytes(big)
+    r = _run(ROUNDTRIP, str(p), str(tmp_path / "y.png"))
+    assert r.returncode == 1 and "too large" in r.stderr
+    import importlib
+    png = importlib.import_module("vulkan_renderer_amd.pngio")
+    with pytest.raises(Exception, match="too large"):
+        png.read_rgba8(str(p))
 
 
 @pytest.mark.parametrize("args,message", [

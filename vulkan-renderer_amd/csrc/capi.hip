@@ -51,7 +51,11 @@ struct State {
     // and read their kernel times afterwards without waiting in between.  ev0 / ev1 are the pair
     // the next timed call records; timed_calls counts the calls that have recorded one.
     hipEvent_t ring0[TIMING_RING] = {}, ring1[TIMING_RING] = {};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // A second pair per call for calls with two pair kernels (the Lambertian call's exact-weights pass
+    // behind its split pass); ring_two says whether the call of a slot recorded it.
+    hipEvent_t ring2[TIMING_RING] = {}, ring3[TIMING_RING] = {};
+    bool ring_two[TIMING_RING] = {};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     uint64_t timed_calls = 0;
     bool timing = false, counting = false, timed_valid = false;
     Buffer a, b, pn, partial, counts, stage_in, stage_out, units, png;
@@ -147,17 +151,22 @@ int create_events(State& st) {
     for (int k = 0; k < TIMING_RING; k++) {
         hipError_t e0 = hipEventCreate(&st.ring0[k]);
         hipError_t e1 = e0 == hipSuccess ? hipEventCreate(&st.ring1[k]) : e0;
+        if (e1 == hipSuccess) e1 = hipEventCreate(&st.ring2[k]);
+        if (e1 == hipSuccess) e1 = hipEventCreate(&st.ring3[k]);
         if (e1 != hipSuccess) {
             for (int j = 0; j <= k; j++) {
-                if (st.ring0[j]) (void)hipEventDestroy(st.ring0[j]);
-                if (st.ring1[j]) (void)hipEventDestroy(st.ring1[j]);
-                st.ring0[j] = st.ring1[j] = nullptr;
+                for (hipEvent_t* ring : {st.ring0, st.ring1, st.ring2, st.ring3}) {
+                    if (ring[j]) (void)hipEventDestroy(ring[j]);
+                    ring[j] = nullptr;
+                }
             }
             return fail(IBL_EHIP, "hipEventCreate: %s", hipGetErrorString(e1));
         }
     }
     st.ev0 = st.ring0[0];
     st.ev1 = st.ring1[0];
+    st.ev2 = st.ring2[0];
+    st.ev3 = st.ring3[0];
     st.timed_calls = 0;
     return IBL_OK;
 }
@@ -182,10 +191,9 @@ int init_device(int device) {
 void drop_state(State& st) {
     release(st.a); release(st.b); release(st.pn); release(st.partial); release(st.counts);
     release(st.stage_in); release(st.stage_out); release(st.units); release(st.png);
-    for (int k = 0; k < TIMING_RING; k++) {
-        if (st.ring0[k]) (void)hipEventDestroy(st.ring0[k]);
-        if (st.ring1[k]) (void)hipEventDestroy(st.ring1[k]);
-    }
+    for (int k = 0; k < TIMING_RING; k++)
+        for (hipEvent_t* ring : {st.ring0, st.ring1, st.ring2, st.ring3})
+            if (ring[k]) (void)hipEventDestroy(ring[k]);
     if (st.stream) (void)hipStreamDestroy(st.stream);
     st = State();
 }
@@ -232,12 +240,29 @@ int check_cube(uint32_t w, uint32_t h, const char* what) {
 }
 
 // A *_dev call that has recorded its event pair: the next timed call gets the next pair.
-void finish_timed_call() {
+// two: the call also recorded the second pair (ev2, ev3).
+void finish_timed_call(bool two = false) {
     S->timed_valid = S->timing;
     if (!S->timing) return;
+    S->ring_two[S->timed_calls % TIMING_RING] = two;
     S->timed_calls++;
     S->ev0 = S->ring0[S->timed_calls % TIMING_RING];
     S->ev1 = S->ring1[S->timed_calls % TIMING_RING];
+    S->ev2 = S->ring2[S->timed_calls % TIMING_RING];
+    S->ev3 = S->ring3[S->timed_calls % TIMING_RING];
+}
+
+// The kernel time of the timed call in a slot of the ring: its pair kernel, plus its second one's.
+int slot_ms(uint64_t slot, float* ms) {
+    HIP_TRY(hipEventSynchronize(S->ring1[slot]));
+    HIP_TRY(hipEventElapsedTime(ms, S->ring0[slot], S->ring1[slot]));
+    if (S->ring_two[slot]) {
+        float more = 0.0f;
+        HIP_TRY(hipEventSynchronize(S->ring3[slot]));
+        HIP_TRY(hipEventElapsedTime(&more, S->ring2[slot], S->ring3[slot]));
+        *ms += more;
+    }
+    return IBL_OK;
 }
 
 int check_range(uint32_t begin, uint32_t count, uint64_t total, const char* what) {
@@ -420,10 +445,7 @@ int ibl_last_kernel_ms(float* ms) {
     if (int rc = check_ready()) return rc;
     if (!ms) return fail(IBL_EINVAL, "ms is null");
     if (!S->timed_valid) return fail(IBL_EINVAL, "no timed kernel: call ibl_set_timing(1) before a *_dev call");
-    const uint64_t slot = (S->timed_calls - 1) % TIMING_RING;
-    HIP_TRY(hipEventSynchronize(S->ring1[slot]));
-    HIP_TRY(hipEventElapsedTime(ms, S->ring0[slot], S->ring1[slot]));
-    return IBL_OK;
+    return slot_ms((S->timed_calls - 1) % TIMING_RING, ms);
 }
 
 int ibl_kernel_ms_back(uint32_t calls_back, float* ms) {
@@ -432,10 +454,7 @@ int ibl_kernel_ms_back(uint32_t calls_back, float* ms) {
     if (calls_back >= (uint32_t)TIMING_RING || calls_back >= S->timed_calls)
         return fail(IBL_EINVAL, "kernel_ms_back: %u calls back, but %llu timed calls so far and %d are kept",
                     calls_back, (unsigned long long)S->timed_calls, TIMING_RING);
-    const uint64_t slot = (S->timed_calls - 1 - calls_back) % TIMING_RING;
-    HIP_TRY(hipEventSynchronize(S->ring1[slot]));
-    HIP_TRY(hipEventElapsedTime(ms, S->ring0[slot], S->ring1[slot]));
-    return IBL_OK;
+    return slot_ms((S->timed_calls - 1 - calls_back) % TIMING_RING, ms);
 }
 
 int ibl_last_counts(uint64_t* patch_tests, uint64_t* tested, uint64_t* accepted) {
@@ -510,8 +529,11 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
         if (int rc = counts_buffer(s, &d_counts)) return rc;
         HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, d_list, 0, n_oct, out_begin, out_count, d_out,
                                            S->a.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
-                                           S->timing ? S->ev1 : nullptr));
+                                           S->timing ? S->ev1 : nullptr, S->timing ? S->ev2 : nullptr,
+                                           S->timing ? S->ev3 : nullptr));
         S->counts_pending = S->counting ? 2 : 0;
+        finish_timed_call(pl.split);
+        return IBL_OK;
     } else {
         ibl::LambertianPlan pl = ibl::lambertian_plan(n_in, out_count);
         if (int rc = ensure(S->a, pl.prep_bytes_a)) return rc;
@@ -557,9 +579,10 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
     if (int rc = counts_buffer(pick(stream), &d_counts)) return rc;
     HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, nullptr, begin, begin + count, 0, n_out, d_out,
                                        S->a.ptr, (double*)S->partial.ptr, d_counts, pick(stream),
-                                       S->timing ? S->ev0 : nullptr, S->timing ? S->ev1 : nullptr));
+                                       S->timing ? S->ev0 : nullptr, S->timing ? S->ev1 : nullptr,
+                                       S->timing ? S->ev2 : nullptr, S->timing ? S->ev3 : nullptr));
     S->counts_pending = S->counting ? 2 : 0;
-    finish_timed_call();
+    finish_timed_call(pl.split);
     return IBL_OK;
 }
 
@@ -592,8 +615,9 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
     unsigned char* base = (unsigned char*)S->static_scratch;
     HIP_TRY(ibl::lambertian_oct_launch(pl, d_env, in_w, out_size, nullptr, 0, n_oct, 0, n_out, d_out, base,
                                        (double*)(base + rec_bytes), nullptr, pick(stream), S->timing ? S->ev0 : nullptr,
-                                       S->timing ? S->ev1 : nullptr));
-    finish_timed_call();
+                                       S->timing ? S->ev1 : nullptr, S->timing ? S->ev2 : nullptr,
+                                       S->timing ? S->ev3 : nullptr));
+    finish_timed_call(pl.split);
     return IBL_OK;
 }
 

@@ -83,11 +83,15 @@ hipError_t octet_units_strided_launch(uint32_t first, uint32_t stride, uint32_t 
 LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks);
 // Output block b of the call is block d_block_list[b] of the tile-major octet order, or, without a
 // list, the 256 octets from oct_begin + 256*b; octets at or past oct_end do not exist.
+// ev0/ev1 bracket the call's first pair kernel (the split form's, or the only one); with the split form
+// in front, ev2/ev3 bracket the exact-weights pair kernel behind it (a few microseconds when it finds
+// nothing marked, about five times the split kernel's time per marked block when it does).
 hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
                                  const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
                                  uint32_t out_begin, uint32_t out_count,
                                  float* d_out, void* d_rec, double* d_partial, unsigned long long* d_counts,
-                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                                 hipEvent_t ev2 = nullptr, hipEvent_t ev3 = nullptr);
 
 struct GgxLevel {          // cube.cpp:161-175
     float roughness, alpha2, cutoff;

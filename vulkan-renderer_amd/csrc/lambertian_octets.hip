@@ -465,7 +465,7 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
                                  const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
                                  uint32_t out_begin, uint32_t out_count,
                                  float* d_out, void* d_rec, double* d_partial, unsigned long long* d_counts,
-                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3) {
     // Split form first: every block at a quarter of the arithmetic, then this file's kernels only
     // for the blocks it marked (none for an environment of ordinary contrast: the launches below
     // then return at once).
@@ -476,7 +476,8 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
             e != hipSuccess) return e;
         d_flags = (const uint32_t*)d_partial;
         d_partial = (double*)((char*)d_partial + lambertian_split_header_bytes(pl.n_oct_in, pl.out_blocks));
-        ev0 = ev1 = nullptr;
+        ev0 = ev2;      // this pass's pair kernel is timed by the call's second pair of events
+        ev1 = ev3;
     }
     const uint32_t oct_local_all = pl.out_blocks * OCT_THREADS;
     lambertian_oct_prep<<<(pl.n_oct_in + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, in_w, pl.n_oct_in,

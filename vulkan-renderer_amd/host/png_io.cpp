@@ -274,6 +274,9 @@ bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, 
         pos += 12 + (size_t)len;
     }
     if (w == 0 || h == 0) { err = "PNG has no IHDR"; return false; }
+    // Every buffer below is sized from w and h.  The largest strip the library takes is 9459 x 56754
+    // (2^31 bytes of RGBA8); anything beyond that is refused here, before a product of the two can wrap.
+    if ((uint64_t)w * h * 4 > 0x80000000ull) { err = "PNG too large (more than 2^31 bytes of RGBA8)"; return false; }
     int channels;
     switch (color) {
         case 0: channels = 1; break;
