@@ -72,7 +72,7 @@ async function build(goals, { dry, jobs }) {
 
 // ---- rule makers (the reference's vocabulary) --------------------------------------------------
 const INC = ['-I' + path.join(ROOT, 'include'), '-I' + path.join(ROOT, PKG, 'csrc')];
-const HIP_HEADERS = [`${PKG}/csrc/ibl_device.h`, `${PKG}/csrc/ibl_kernels.h`, 'include/ibl_hip.h'];
+const HIP_HEADERS = [`${PKG}/csrc/ibl_device.h`, `${PKG}/csrc/ibl_kernels.h`, `${PKG}/csrc/ggx_common.h`, 'include/ibl_hip.h'];
 
 // A kernel source to an object for gfx950.
 function HIP(src, extra = []) {
@@ -94,7 +94,7 @@ function LINK(objs, out, { linker = CXX, flags = [], libs = [], deps = [] } = {}
 }
 
 // ---- the targets ---------------------------------------------------------------------------------
-const kernels = ['lambertian', 'lambertian_octets', 'ggx', 'ggx_octets', 'ggx_sampled', 'lut_codec', 'png_rows',
+const kernels = ['lambertian', 'lambertian_octets', 'ggx', 'ggx_octets', 'ggx_hex', 'ggx_sampled', 'lut_codec', 'png_rows',
                  'sharding', 'mirror_reproject', 'capi'].map((k) => HIP(`${PKG}/csrc/${k}.hip`));
 // (the SLP vectoriser turns this kernel's scalar adds into packed adds plus the moves that feed them)
 kernels.push(HIP(`${PKG}/csrc/lambertian_split.hip`, ['-fno-slp-vectorize']));

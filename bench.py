@@ -67,6 +67,11 @@ GGX_FLOP_PER_LANE_EVALUATED = 62
 GGX_MX_FLOP_PER_LANE_EVALUATED = 17
 GGX_MX_RSQ_FLOP_PER_LANE_EVALUATED = 20
 GGX_MX_MATRIX_FLOP_PER_LANE_RECORD = 192
+# The 16-fold kernel (ggx_hex_pairs: sign flips and the exchange of x and y; the default where the output
+# faces are a multiple of 16 wide) evaluates the same weight per lane and record -- the same vector
+# instructions -- and multiplies it into 64 record columns instead of 32: 384 per lane and record on the
+# matrix pipe; a weight then serves 16 texel pairs instead of 8.
+GGX_HEX_MATRIX_FLOP_PER_LANE_RECORD = 384
 BF16_MATRIX_PEAK_TFLOPS = 2500.0
 FLOP_PER_GGX_ACCEPTED = 30          # pair by pair
 FLOP_PER_GGX_REJECTED = 8
@@ -189,10 +194,9 @@ class Workload:
             self.matrix = (ibl.get_tuning("ggx_matrix") != 0 and self.env_w >= 64 and not args.ggx_samples
                            and bool(lv1["my_wave_records"]))
             self.matrix_flop_per_launch = None
-            # the same level on the vector pipe alone (ggx_matrix 0): what chain_extra's FP32 run executes
-            self.vector_executed_flop_per_launch = (64.0 * (GGX_FLOP_PER_LANE_WALKED * lv1["my_wave_records"]
-                                                            + GGX_FLOP_PER_LANE_EVALUATED * lv1["my_wave_evaluated"])
-                                                    if lv1["my_wave_records"] else None)
+            # the 16-fold kernel serves level 1 (the library's rule: ggx_hex_eligible)
+            self.hex = (self.matrix and ibl.get_tuning("ggx_hex") != 0 and lv1["ow"] % 16 == 0 and lv1["ow"] >= 32
+                        and (self.env_w & (self.env_w - 1)) == 0)
             if lv1["my_wave_records"] and self.matrix:
                 # which weight form level 1 takes: the library's rule (ggx_oct_launch)
                 rsq_knob = ibl.get_tuning("ggx_rsq")
@@ -200,11 +204,13 @@ class Workload:
                 self.rsq = narrow and (rsq_knob == 2 or (rsq_knob == 1 and self.env_w >= 1024))
                 per_record = GGX_MX_RSQ_FLOP_PER_LANE_EVALUATED if self.rsq else GGX_MX_FLOP_PER_LANE_EVALUATED
                 self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED + per_record) * lv1["my_wave_records"]
-                self.matrix_flop_per_launch = 64.0 * GGX_MX_MATRIX_FLOP_PER_LANE_RECORD * lv1["my_wave_records"]
+                self.matrix_flop_per_launch = 64.0 * lv1["my_wave_records"] * (
+                    GGX_HEX_MATRIX_FLOP_PER_LANE_RECORD if self.hex else GGX_MX_MATRIX_FLOP_PER_LANE_RECORD)
             elif lv1["my_wave_records"]:
                 self.executed_flop_per_launch = 64.0 * (GGX_FLOP_PER_LANE_WALKED * lv1["my_wave_records"]
                                                         + GGX_FLOP_PER_LANE_EVALUATED * lv1["my_wave_evaluated"])
-            self.kernel = "ggx_oct_pairs%s (level 1)" % (", matrix form" if self.matrix else "")
+            self.kernel = ("ggx_hex_pairs (level 1)" if self.hex else
+                           "ggx_oct_pairs%s (level 1)" % (", matrix form" if self.matrix else ""))
             self.desc = ("C%s: GGX prefilter chain of a %dx%d/face environment, %d levels, --input-downscale %d; "
                          "samples = in-patch texel tests (%.3g tested, %.3g accepted)"
                          % (name[1], self.in_w, self.in_w, self.mips, self.down, tested, accepted))
@@ -436,16 +442,27 @@ def chain_extra(name, args, ibl, rank, world, dist, torch, steps, cpu_seconds):
     if getattr(wl, "matrix", False):
         # Like for like with the reference, which multiplies in FP32: the same chain with the sums on the vector
         # pipe (ggx_matrix 0), timed the same way in the same run.
+        out[name + "_kernel"] = wl.kernel
         out[name + "_products"] = ("2 bf16 pieces per factor (16 significant bits) on the matrix pipe; patches whose "
-                                   "radiance sits in a few texels: FP32 on the vector pipe")
+                                   "radiance sits in a few texels: 3 pieces per factor, every product to 2^-25")
         ibl.set_tuning("ggx_matrix", 0)
         try:
+            # what the vector form of level 1 executes, counted by its own counting variant
+            lv1 = wl.levels[0]
+            ibl.set_counting(True)
+            ibl.ggx_level_shard(wl.env, lv1["ow"], lv1["m"], wl.mips, rank, world, out=lv1["out"])
+            c = ibl.last_counts()
+            ibl.set_counting(False)
+            wl.vector_executed_flop_per_launch = (64.0 * (GGX_FLOP_PER_LANE_WALKED * c["wave_records"]
+                                                          + GGX_FLOP_PER_LANE_EVALUATED * c["wave_patterns"])
+                                                  if c["wave_records"] else None)
             wl.kernel_ms.clear()
             f_steps = max(1, steps // 2)
             f_elapsed, f_kernel_ms = run_timed(wl, f_steps, 1, torch, dist, world, ibl.device)
         finally:
             ibl.set_tuning("ggx_matrix", 1)
         f_chain = f_elapsed / f_steps
+        out[name + "_fp32_kernel"] = "ggx_oct_pairs, vector form"
         out[name + "_fp32_products"] = "FP32 on the vector pipe throughout (ggx_matrix 0)"
         out[name + "_fp32_steps"] = f_steps
         out[name + "_fp32_ms_per_chain"] = round(f_chain * 1e3, 3)

@@ -26,7 +26,7 @@ def test_dry_run_lists_every_rule(tmp_path):
     lines = r.stdout.strip().splitlines()
     hip = [l for l in lines if "--offload-arch=gfx950" in l and " -c " in l]
     sources = sorted(f for f in os.listdir(os.path.join(ROOT, "vulkan-renderer_amd", "csrc")) if f.endswith(".hip"))
-    assert len(hip) == len(sources) == 11
+    assert len(hip) == len(sources) == 12
     for s in sources:
         assert any(l.rstrip().split(" -o ")[0].endswith(s) for l in hip), s
     assert any("lambertian_split.hip" in l and "-fno-slp-vectorize" in l for l in hip)

@@ -137,6 +137,7 @@ void read_tuning_once() {
     if (const char* e = getenv("IBL_GGX_CORE")) g_tuning.ggx_core = (float)atof(e);
     if (const char* e = getenv("IBL_GGX_MATRIX")) g_tuning.ggx_matrix = atoi(e);
     if (const char* e = getenv("IBL_GGX_RSQ")) g_tuning.ggx_rsq = atoi(e);
+    if (const char* e = getenv("IBL_GGX_HEX")) g_tuning.ggx_hex = atoi(e);
     if (const char* e = getenv("IBL_GGX_FEW")) g_tuning.ggx_few = (float)atof(e);
 }
 
@@ -353,6 +354,7 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "ggx_early")) g_tuning.ggx_early = (int)value;
     else if (!strcmp(name, "ggx_matrix")) g_tuning.ggx_matrix = (int)value;
     else if (!strcmp(name, "ggx_rsq")) g_tuning.ggx_rsq = (int)value;
+    else if (!strcmp(name, "ggx_hex")) g_tuning.ggx_hex = (int)value;
     else if (!strcmp(name, "ggx_few")) g_tuning.ggx_few = (float)value;
     else if (!strcmp(name, "ggx_sums_mib")) g_tuning.ggx_sums_mib = value;
     else if (!strcmp(name, "bake_rehearse_shards")) g_tuning.bake_rehearse_shards = (int)value;
@@ -376,6 +378,7 @@ int ibl_get_tuning(const char* name, double* value) {
     else if (!strcmp(name, "ggx_early")) *value = g_tuning.ggx_early;
     else if (!strcmp(name, "ggx_matrix")) *value = g_tuning.ggx_matrix;
     else if (!strcmp(name, "ggx_rsq")) *value = g_tuning.ggx_rsq;
+    else if (!strcmp(name, "ggx_hex")) *value = g_tuning.ggx_hex;
     else if (!strcmp(name, "ggx_few")) *value = g_tuning.ggx_few;
     else if (!strcmp(name, "ggx_sums_mib")) *value = g_tuning.ggx_sums_mib;
     else if (!strcmp(name, "bake_rehearse_shards")) *value = g_tuning.bake_rehearse_shards;
@@ -420,7 +423,9 @@ int ibl_ggx_level_plan(uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32
     if (g_tuning.no_octets || !ibl::ggx_octets_eligible(in_w, out_w, lv.patch))
         return fail(IBL_EINVAL, "ggx_level_plan: faces %u -> %u are served by the general kernel", in_w, out_w);
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
-    const ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, (n_oct + ibl::GGX_OCT_UNIT - 1) / ibl::GGX_OCT_UNIT);
+    const bool hex = g_tuning.ggx_hex != 0 && g_tuning.ggx_matrix != 0 && ibl::ggx_hex_eligible(in_w, out_w, lv.patch);
+    const ibl::GgxOctPlan pl = hex ? ibl::ggx_hex_plan(in_w, out_w, mip_level, mip_levels, ibl::ggx_hex_units_total(out_w))
+                                   : ibl::ggx_oct_plan(in_w, out_w, mip_level, mip_levels, (n_oct + ibl::GGX_OCT_UNIT - 1) / ibl::GGX_OCT_UNIT);
     if (runs) *runs = pl.n_runs;
     if (passes) *passes = pl.passes;
     if (sums_bytes) *sums_bytes = pl.partial_bytes;
@@ -647,6 +652,39 @@ bool use_ggx_octets(uint32_t in_w, uint32_t out_w, uint32_t patch) {
     return ibl::ggx_octets_eligible(in_w, out_w, patch);
 }
 
+// The 16-fold kernel serves the level: mirror-exact sizes, output faces a multiple of 16 wide, the matrix form
+// switched on (it has no vector form of its own).
+bool use_ggx_hex(uint32_t in_w, uint32_t out_w, uint32_t patch) {
+    if (g_tuning.no_octets || g_tuning.ggx_hex == 0 || g_tuning.ggx_matrix == 0) return false;
+    return ibl::ggx_hex_eligible(in_w, out_w, patch);
+}
+
+int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                   uint32_t n_units, uint32_t out_begin, uint32_t out_count, float* d_out, hipStream_t s);
+
+// The 16-fold kernel over the n_units units of 64 hexadecets listed in S->units.  When counting, the octet
+// kernel's counting variant runs first over the octet units listed behind them (n_oct_units; its counts of
+// texel tests are the reference's), and the records this kernel walks replace that variant's.
+int ggx_run_hex(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
+                uint32_t n_units, uint32_t out_begin, uint32_t out_count, float* d_out, hipStream_t s) {
+    ibl::GgxOctPlan pl = ibl::ggx_hex_plan(in_w, out_w, mip_level, mip_levels, n_units);
+    if (pl.out_units == 0) { S->timed_valid = false; return IBL_OK; }
+    if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
+    if (int rc = ensure(S->pn, pl.pn_bytes)) return rc;
+    if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+    unsigned long long* d_counts = nullptr;
+    if (S->counting) {
+        d_counts = (unsigned long long*)S->counts.ptr;          // (the counting pass before this call made and zeroed it)
+        HIP_TRY(hipMemsetAsync(d_counts + 3, 0, 2 * sizeof(unsigned long long), s));
+    }
+    HIP_TRY(ibl::ggx_hex_launch(pl, d_env, in_w, out_w, (const uint32_t*)S->units.ptr, out_begin, out_count, d_out,
+                                S->a.ptr, S->pn.ptr, (double*)S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
+                                S->timing ? S->ev1 : nullptr));
+    finish_timed_call();
+    S->counts_pending = S->counting ? 1 : 0;
+    return IBL_OK;
+}
+
 // Octet kernel over the n_units 64-octet units listed in S->units, writing the member texels
 // inside [out_begin, out_begin+out_count).
 int ggx_run_octets(const float* d_env, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32_t mip_levels,
@@ -683,9 +721,13 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
     S->counts_pending = 0;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
     hipStream_t s = pick(stream);
-    if (use_ggx_octets(in_w, out_w, patch)) {
+    const bool hex = use_ggx_hex(in_w, out_w, patch);
+    if (use_ggx_octets(in_w, out_w, patch) && (!hex || S->counting)) {
         // the 64-octet units that hold a texel of the range; the other members of their octets
         // are computed and not stored
+        // (counting with the 16-fold kernel: the octet kernel's counting variant first, whose counts of
+        // texel tests are the reference's; the 16-fold kernel then overwrites the texels and counts the
+        // records it walks itself)
         const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2), total = (n_oct + ibl::GGX_OCT_UNIT - 1) / ibl::GGX_OCT_UNIT;
         uint32_t n_units = total;
         if (int rc = ensure(S->units, (size_t)total * sizeof(uint32_t))) return rc;
@@ -697,7 +739,20 @@ int ibl_ggx_level_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t
             HIP_TRY(ibl::octet_units_in_range_launch(ibl::GGX_OCT_UNIT, out_w, tw, out_begin, out_count,
                                                      (uint32_t*)S->units.ptr, s));
         }
-        return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, n_units, out_begin, out_count, d_out, s);
+        const int rc = ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, n_units, out_begin, out_count, d_out, s);
+        if (rc || !hex) return rc;
+    }
+    if (hex) {
+        const uint32_t total = ibl::ggx_hex_units_total(out_w);
+        uint32_t n_units = total;
+        if (int rc = ensure(S->units, (size_t)total * sizeof(uint32_t))) return rc;
+        if (out_begin == 0 && out_count == n_out) {
+            HIP_TRY(ibl::octet_units_strided_launch(0, 1, total, (uint32_t*)S->units.ptr, s));
+        } else {
+            n_units = ibl::ggx_hex_units_in_range_count(out_w, out_begin, out_count);
+            HIP_TRY(ibl::ggx_hex_units_in_range_launch(out_w, out_begin, out_count, (uint32_t*)S->units.ptr, s));
+        }
+        return ggx_run_hex(d_env, in_w, out_w, mip_level, mip_levels, n_units, out_begin, out_count, d_out, s);
     }
     ibl::GgxPlan pl = ibl::ggx_plan(in_w, in_h, out_w, out_h, mip_level, mip_levels, out_count);
     if (int rc = ensure(S->a, pl.prep_bytes_a)) return rc;
@@ -734,14 +789,33 @@ int ibl_ggx_level_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, ui
     const uint32_t n_oct = 3 * (out_w / 2) * (out_w / 2);
     const uint32_t n_units = (n_oct + 63) / 64;
     const uint32_t mine = shard < n_units ? (n_units - shard + n_shards - 1) / n_shards : 0;
+    const bool hex = use_ggx_hex(in_w, out_w, patch);
     S->last_counts[0] = (uint64_t)mine * 64 * 8 * n_patches;
     S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
     S->last_counts[1] = S->last_counts[2] = 0;
     S->counts_pending = 0;
-    if (mine == 0) { S->timed_valid = false; return IBL_OK; }
-    if (int rc = ensure(S->units, (size_t)mine * sizeof(uint32_t))) return rc;
-    HIP_TRY(ibl::octet_units_strided_launch(shard, n_shards, mine, (uint32_t*)S->units.ptr, pick(stream)));
-    return ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, mine, 0, n_out, d_out, pick(stream));
+    if (!hex || S->counting) {
+        // (counting with the 16-fold kernel: the counting variant of the octet kernel on the octet shard first --
+        // its texels are other texels than the hexadecet shard's, the shards' counts add up to the level's all the same)
+        if (mine == 0) {
+            S->timed_valid = false;
+            if (!hex) return IBL_OK;
+            unsigned long long* zeroed = nullptr;          // (no octet unit to count on: the counters start at 0)
+            if (int rc = counts_buffer(pick(stream), &zeroed)) return rc;
+        } else {
+            if (int rc = ensure(S->units, (size_t)mine * sizeof(uint32_t))) return rc;
+            HIP_TRY(ibl::octet_units_strided_launch(shard, n_shards, mine, (uint32_t*)S->units.ptr, pick(stream)));
+            const int rc = ggx_run_octets(d_env, in_w, out_w, mip_level, mip_levels, mine, 0, n_out, d_out, pick(stream));
+            if (rc || !hex) return rc;
+        }
+    }
+    // the same with units of 64 hexadecets
+    const uint32_t hex_units = ibl::ggx_hex_units_total(out_w);
+    const uint32_t hex_mine = shard < hex_units ? (hex_units - shard + n_shards - 1) / n_shards : 0;
+    if (hex_mine == 0) { S->timed_valid = false; return IBL_OK; }
+    if (int rc = ensure(S->units, (size_t)hex_mine * sizeof(uint32_t))) return rc;
+    HIP_TRY(ibl::octet_units_strided_launch(shard, n_shards, hex_mine, (uint32_t*)S->units.ptr, pick(stream)));
+    return ggx_run_hex(d_env, in_w, out_w, mip_level, mip_levels, hex_mine, 0, n_out, d_out, pick(stream));
 }
 
 // Sizes the current device's workspaces for whole-cube Lambertian calls in_w -> lambertian_size
@@ -773,7 +847,14 @@ int ibl_reserve(uint32_t in_w, uint32_t lambertian_size, uint32_t ggx_top_w, uin
             const uint32_t ow = ggx_top_w >> m;
             if (ow == 0) break;
             const ibl::GgxLevel lv = ibl::ggx_level_params(m, mips, in_w, in_w);
-            if (!g_tuning.no_octets && ibl::ggx_octets_eligible(in_w, ow, lv.patch)) {
+            if (use_ggx_hex(in_w, ow, lv.patch) && !S->counting) {
+                const uint32_t units = ibl::ggx_hex_units_total(ow);
+                ibl::GgxOctPlan pl = ibl::ggx_hex_plan(in_w, ow, m, mips, units);
+                if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
+                if (int rc = ensure(S->pn, pl.pn_bytes)) return rc;
+                if (int rc = ensure(S->partial, pl.partial_bytes)) return rc;
+                if (int rc = ensure(S->units, (size_t)units * sizeof(uint32_t))) return rc;
+            } else if (!g_tuning.no_octets && ibl::ggx_octets_eligible(in_w, ow, lv.patch)) {
                 const uint32_t n_oct = 3 * (ow / 2) * (ow / 2), units = (n_oct + ibl::GGX_OCT_UNIT - 1) / ibl::GGX_OCT_UNIT;
                 ibl::GgxOctPlan pl = ibl::ggx_oct_plan(in_w, ow, m, mips, units);
                 if (int rc = ensure(S->a, pl.rec_bytes)) return rc;
@@ -817,7 +898,9 @@ int shard_map(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint3
         if (mip_levels == 0 || mip_level == 0 || mip_level > mip_levels)
             return fail(IBL_EINVAL, "ggx: level %u of %u is out of range", mip_level, mip_levels);
         const ibl::GgxLevel lv = ibl::ggx_level_params(mip_level, mip_levels, in_w, in_w);
-        if (!g_tuning.no_octets && ibl::ggx_octets_eligible(in_w, out_w, lv.patch)) {
+        if (use_ggx_hex(in_w, out_w, lv.patch)) {
+            m->partition = ibl::SHARD_GGX_HEX;
+        } else if (!g_tuning.no_octets && ibl::ggx_octets_eligible(in_w, out_w, lv.patch)) {
             m->partition = ibl::SHARD_GGX_OCT;
             m->tw = ibl::ggx_oct_tile_edge(out_w);
         }

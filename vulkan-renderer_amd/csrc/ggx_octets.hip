@@ -39,21 +39,16 @@
 // stores decides only which waves run and what they store, never how a wave adds.
 #include "ibl_device.h"
 #include "ibl_kernels.h"
+#include "ggx_common.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
 
 namespace ibl {
 
-constexpr int GO_THREADS = 256;         // threads per workgroup of the small kernels
 constexpr int GO_UNIT = 64;             // output octets per wave: the unit of sharding
-#ifndef GO_WG
-#define GO_WG 64                        // threads per workgroup of ggx_oct_pairs (waves are independent)
-#endif
 constexpr int GO_REC = 7;              // float4 per texel-octet record
 constexpr int GO_SUMS = 25;             // doubles per (slice, output octet): 8 members x RGB + the weight sum
-constexpr int GO_CHUNK = 256;          // most terms an FP32 chunk sum may hold
-constexpr int GO_MARK_PART = 64;       // records per walk over a marked patch octet (ggx_oct_pairs<.., MARKS = 2>)
 
 // Output octets are numbered tile-major: tiles of tw x tw canonical positions.
 __host__ __device__ inline uint32_t go_tile_edge(uint32_t hw) {
@@ -186,9 +181,6 @@ __global__ __launch_bounds__(1024) void ggx_oct_list_marks(uint32_t n_po, float4
 // early-clobber (they are written long after the instruction has issued, so they must not share
 // a register with the address); go_rec_wait ties the registers to the wait, so that no use can
 // be scheduled in front of it.
-typedef uint32_t go_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t go_u32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t go_u32x16 __attribute__((ext_vector_type(16)));
 struct GoRec { go_u32x4 a; go_u32x16 b; go_u32x8 c; };     // float4 0 | 1-4 | 5-6 of the record
 
 __device__ __forceinline__ void go_rec_load(GoRec& r, const float4* __restrict__ p) {
@@ -220,15 +212,7 @@ __device__ __forceinline__ void go_unpack(const GoRec& s, float (&r)[28]) {
 // form, four records to a 64-byte block (x0-3, y0-3, z0-3, |w|^-3 0-3: neighbouring records' components
 // are then scalar register pairs for packed instructions); then per 16 consecutive records two 1 KB tiles (upper pieces, lower pieces) in the B-operand
 // order of the instruction: lane l holds column l % 32 of records 8 (l / 32) + 0..7 as 8 bf16.
-typedef float go_f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 go_bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int GO_MX_GROUP = 16;                       // records per matrix instruction
 constexpr int GO_MX_REC_BYTES = 16 + 2 * 64;          // direction + two pieces of 32 columns
-
-__device__ __forceinline__ uint32_t go_bf16_bits(float x) {          // nearest even; finite x
-    const uint32_t b = __float_as_uint(x);
-    return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
-}
 
 __global__ __launch_bounds__(256) void ggx_mx_prep(const float4* __restrict__ env, uint32_t w, uint32_t ps,
                                                     uint32_t n_rec, float4* __restrict__ dirs, go_u32x4* __restrict__ tiles) {
@@ -275,114 +259,6 @@ __global__ __launch_bounds__(256) void ggx_mx_prep(const float4* __restrict__ en
     tiles[(size_t)(grp * 2 + 1) * 64 + l] = b;
 }
 
-// Four records' directions (float4 each) in scalar registers (matrix form).
-struct GoDir4 { go_u32x16 v; };
-__device__ __forceinline__ void go_dir_load(GoDir4& r, const float4* __restrict__ p) {
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(r.v) : "s"(p));
-}
-__device__ __forceinline__ void go_dir_wait(GoDir4& r) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.v));
-}
-// bf16(a) in the lower half, bf16(b) in the upper half, nearest even (v_cvt_pk_bf16_f32; as a
-// conversion the compiler sees, so that it keeps the wait states of the lane swap that reads it).
-__device__ __forceinline__ uint32_t go_pack_bf16(float a, float b) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const f32x2 v = { a, b };
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
-struct GoConst {
-    float cutoff, om_a2, cmin;
-    float core_thr;   // below this denominator the reference's own rounding is reproduced (0: never)
-};
-
-// One record under one sign pattern: weight from the cosine, added to the sums of all 8 members.
-// The pattern enters only through nt, the output direction with the pattern's signs applied
-// (the cosine of output member so with input member si = so ^ tau is nt . u for every so), and
-// through the bookkeeping of the caller: acc is indexed by the INPUT member, and the caller adds
-// acc[si] to output member si ^ tau when it folds the chunk into the running sums.
-// CORE: some lane of the wave may be inside the lobe core for this patch (see below).
-template <bool COUNT, bool CORE>
-__device__ __forceinline__ float go_weight(float c, float ux, float uy, float uz, float thr, float a2p, const GoConst& k,
-                                           const F3& nt, uint32_t& n_acc) {
-    float u = fmaf(-0.5f, c, 0.5f);
-    float t = 1.0f - u;
-    float sq = __builtin_amdgcn_sqrtf(t);
-    float d = fmaf(u, k.om_a2, a2p);
-    // At the centre of a narrow lobe d cancels to ~a2, the weight ~1/d^2 amplifies the
-    // reference's float rounding of NoH^2 (about 1e-7/a2 per pair), and that rounding is
-    // not zero-mean there (1/sqrt of |half|^2 just below 4 lands on rounding ties).  Inside
-    // the lobe core the denominator is therefore recomputed with the reference's exact
-    // operation sequence (flipping the signs of n instead of those of u flips the signs of
-    // the half vector's components and changes no product, sum or rounding).  Output tiles
-    // are small against the core, so the branch is nearly wave-uniform; patches too far from
-    // the wave's directions to reach the core are walked without the test (CORE = false).
-    if (CORE) {
-        const bool core = d < k.core_thr;
-        if (__any(core)) {
-            F3 uu = { ux, uy, uz };
-            float den = ref_ggx_denominator(uu, nt, -k.om_a2);
-            d = core ? den : d;
-        }
-    }
-    float f;
-    if (COUNT) {            // thr: this lane's acceptance threshold on the cosine (2 if its patch test failed)
-        float qd = (t - k.cutoff) * __builtin_amdgcn_rcpf(d);
-        f = (c * sq) * (qd * qd);
-        bool ok = c > thr;
-        f = ok ? f : 0.0f;
-        n_acc += ok ? 1u : 0u;
-    } else {
-        // thr: this lane's cutoff (2 if its patch test failed).  The two acceptance tests of
-        // cube.cpp:271 are folded into output clamps: t - cutoff <= 0 outside the window and
-        // c * sqrt(t) <= 0 below the horizon both give weight 0, and the weight goes to 0
-        // continuously at either edge, so no compare and no select are needed.
-        float qd = sub_clamp01(t, thr) * __builtin_amdgcn_rcpf(d);
-        f = mul_clamp01(c, sq) * (qd * qd);
-    }
-    return f;
-}
-
-// Four records at once (matrix form, patches away from the lobe core): the same operations in the
-// same order as go_weight, the multiplies, adds and FMAs as v_pk_*_f32 on a 4-vector, which the
-// compiler issues as two packed instructions per operation, the halves alternating -- so that no
-// packed instruction reads the result of the one right before it (the compiler puts a wait state
-// between two such, and a wait state costs an issue slot like any instruction).
-// NARROW (cutoff > 1/2, i.e. the acceptance window ends above the horizon): a texel inside the
-// window has a positive cosine, so the horizon clamp of c sqrt(t) has nothing to do, and
-// sqrt(t) / d^2 is taken as t rsq(t d^4): one half-rate instruction per record instead of two
-// (v_sqrt_f32, v_rcp_f32) and no unpacked multiply, for three more packed multiplies per pair.
-// t d^4 cannot be 0 (the smallest normal float is added: d >= alpha^2 > 1e-4, so it changes no
-// value above 1e-30, and at t = 0, where the window's clamp has long made the weight 0, it keeps
-// rsq finite).
-typedef float go_f32x4 __attribute__((ext_vector_type(4)));
-template <bool NARROW>
-__device__ __forceinline__ go_f32x4 go_weight_quad(go_f32x4 c, float thr, float a2p, const GoConst& k) {
-    const go_f32x4 half = { 0.5f, 0.5f, 0.5f, 0.5f }, mhalf = -half;
-    const go_f32x4 om = { k.om_a2, k.om_a2, k.om_a2, k.om_a2 }, a2 = { a2p, a2p, a2p, a2p };
-    go_f32x4 u = __builtin_elementwise_fma(mhalf, c, half);
-    go_f32x4 t = __builtin_elementwise_fma(half, c, half);      // (as 1 - u the compiler issues four unpacked subtractions)
-    go_f32x4 d = __builtin_elementwise_fma(u, om, a2);
-    const go_f32x4 cw = { sub_clamp01(t.x, thr), sub_clamp01(t.y, thr), sub_clamp01(t.z, thr), sub_clamp01(t.w, thr) };
-    if constexpr (NARROW) {
-        const float tn = 1.1754944e-38f;
-        const go_f32x4 tiny = { tn, tn, tn, tn };
-        const go_f32x4 d2 = d * d;
-        const go_f32x4 e = __builtin_elementwise_fma(t * d2, d2, tiny);
-        const go_f32x4 r = { __builtin_amdgcn_rsqf(e.x), __builtin_amdgcn_rsqf(e.y), __builtin_amdgcn_rsqf(e.z),
-                             __builtin_amdgcn_rsqf(e.w) };
-        return c * ((cw * cw) * (t * r));
-    } else {
-        const go_f32x4 sq = { __builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y), __builtin_amdgcn_sqrtf(t.z),
-                              __builtin_amdgcn_sqrtf(t.w) };
-        const go_f32x4 rd = { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z),
-                              __builtin_amdgcn_rcpf(d.w) };
-        go_f32x4 qd = cw * rd;
-        const go_f32x4 m = { mul_clamp01(c.x, sq.x), mul_clamp01(c.y, sq.y), mul_clamp01(c.z, sq.z), mul_clamp01(c.w, sq.w) };
-        return m * (qd * qd);
-    }
-}
 
 template <bool COUNT, bool CORE>
 __device__ __forceinline__ void go_body(float c, const float (&r)[28], float thr, float a2p, const GoConst& k,
@@ -925,30 +801,24 @@ bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch) {
 
 uint32_t ggx_oct_tile_edge(uint32_t out_w) { return go_tile_edge(out_w / 2); }
 
-GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t n_units) {
-    GgxOctPlan pl;
+// The runs of a level, the launches they are spread over and the bytes of their sums, for a kernel whose
+// waves each own 64 lanes of output (octets, or hexadecets in ggx_hex.hip) with `sums` FP32 sums per lane
+// and `members` texels behind a lane and behind a record, `patterns` = members.  pl.lv, pl.n_po and
+// pl.matrix are set by the caller; lanes_level and units_level describe the whole level (runs and
+// subsets come from the level geometry only: range/shard independence), n_units the call.
+void ggx_plan_runs(GgxOctPlan& pl, uint32_t lanes_level, uint32_t units_level, uint32_t members, uint32_t sums,
+                   size_t rec_each, uint32_t n_units) {
     pl.accumulate = false;
-    pl.lv = ggx_level_params(mip, mips, in_w, in_w);
-    const uint32_t ps = pl.lv.patch, pw = in_w / ps;
-    pl.n_po = 3 * (pw / 2) * (pw / 2);
-    pl.tw = go_tile_edge(out_w / 2);
-    // Runs and subsets come from the level geometry only (range/shard independence).
-    const uint32_t n_oct_level = 3 * (out_w / 2) * (out_w / 2);
-    const uint32_t units_level = (n_oct_level + GO_UNIT - 1) / GO_UNIT;      // one wave each per run
+    const uint32_t ps = pl.lv.patch;
     // Enough waves that an eighth of the level (one of 8 GPUs) still fills a GPU (6144 wave
     // slots each) a few times over: 65536.  Large levels get up to sixteen times that, as far
-    // as their work can carry the partial sums (every (wave, run) writes 64 x 25 floats; that
+    // as their work can carry the partial sums (every (wave, run) writes 64 x `sums` floats; that
     // traffic is kept to a few per cent of the estimated run time).
     const double cmin = fmax(0.0, 2.0 * (double)pl.lv.cutoff - 1.0);
     const double cone = 0.5 * (1.0 - cmin);                              // accepted share of the sphere
-    // The matrix form takes whole groups of 16 records (inputs of 64 x 64 and more).  It cannot drop
-    // single records after their cosine as EARLY does at wide lobes, and is still the faster one there
-    // (2048 -> 256: 323 ms against 462; 512 -> 64: 1.64 against 2.16).
-    pl.matrix = tuning().ggx_matrix != 0 && (ps * ps) % GO_MX_GROUP == 0;
-    const size_t rec_each = pl.matrix ? (size_t)GO_MX_REC_BYTES : GO_REC * sizeof(float4);
-    const double wave_records = (double)n_oct_level / 64.0 * (double)pl.n_po * ps * ps * 8.0 * cone;
+    const double wave_records = (double)lanes_level / 64.0 * (double)pl.n_po * ps * ps * (double)members * cone;
     const double seconds = wave_records * 70e-9 / 1024.0;                // ~70 ns per wave, record and pattern per SIMD
-    double waves = 0.04 * seconds * 1.5e12 / (64.0 * GO_SUMS * 4.0);
+    double waves = 0.04 * seconds * 1.5e12 / (64.0 * sums * 4.0);
     waves = fmin(fmax(waves, 65536.0), 1048576.0);
     if (tuning().ggx_waves > 0.0) waves = tuning().ggx_waves;            // tuning knob
     uint32_t want = (uint32_t)ceil(waves / (double)units_level);
@@ -960,17 +830,17 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     // 4 GiB by launching the runs in several passes (below).
     {
         const double rec_total = (double)pl.n_po * ps * ps * (double)rec_each;
-        const double per_run = (double)units_level * GO_UNIT * GO_SUMS * sizeof(float);
+        const double per_run = (double)units_level * GO_UNIT * sums * sizeof(float);
         const double fit = ceil(rec_total / (double)(4u << 20));
         // ... and the partial sums should not be many times the bytes the level has to move anyway
         // (32 per input texel, 16 per output texel): at most 8 times those.
-        const double algorithmic = 32.0 * pl.n_po * ps * ps * 8.0 + 16.0 * n_oct_level * 8.0;
+        const double algorithmic = 32.0 * pl.n_po * ps * ps * (double)members + 16.0 * lanes_level * (double)members;
         const double modest = floor(8.0 * algorithmic / per_run);
         if (tuning().ggx_waves <= 0.0) {
             if ((double)want > modest) want = modest >= 1.0 ? (uint32_t)modest : 1u;
             if (fit > (double)want) want = (uint32_t)fit;
         }
-        uint32_t max_runs = pl.n_po < 32000u ? pl.n_po : 32000u;     // at least one patch octet per run; the run numbers travel in 15 bits
+        uint32_t max_runs = pl.n_po < 32000u ? pl.n_po : 32000u;     // at least one patch per run; the run numbers travel in 15 bits
         if (max_runs == 0) max_runs = 1;
         uint32_t runs = want < 1 ? 1 : (want > max_runs ? max_runs : want);
         // The sums of one launch's runs (FP32) and of the groups of runs (FP64) together stay below
@@ -980,7 +850,7 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
         // launch has a multiple of 8 runs, so that the 8 XCDs can own equal shares of them (see
         // ggx_oct_pairs).  Levels too large even for 8 runs at a time (8192 -> 4096: 1.3 GB per run)
         // launch what fits and add every launch into one set of FP64 sums (below).
-        const double elems = (double)units_level * GO_UNIT * GO_SUMS;
+        const double elems = (double)units_level * GO_UNIT * sums;
         const double budget = tuning().ggx_sums_mib > 0.0 ? tuning().ggx_sums_mib * 1048576.0 : (double)(4ull << 30);
         auto groups_of = [](uint32_t n) { uint32_t g = n > 64 ? (n + 31) / 32 : 1; return g > 64 ? 64u : g; };
         auto single_fits = [&](uint32_t n) {
@@ -1035,7 +905,24 @@ GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
         pl.per_group = (pl.n_runs + pl.reduce_groups - 1) / pl.reduce_groups;
     }
     const uint32_t stage2 = pl.accumulate ? 1 : (pl.reduce_groups > 1 ? pl.reduce_groups : 0);
-    pl.partial_bytes = (size_t)GO_SUMS * oct_count * (pl.runs_per_pass * sizeof(float) + stage2 * sizeof(double));
+    pl.partial_bytes = (size_t)sums * oct_count * (pl.runs_per_pass * sizeof(float) + stage2 * sizeof(double));
+}
+
+GgxOctPlan ggx_oct_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t n_units) {
+    GgxOctPlan pl;
+    pl.hex = false;
+    pl.lv = ggx_level_params(mip, mips, in_w, in_w);
+    const uint32_t ps = pl.lv.patch, pw = in_w / ps;
+    pl.n_po = 3 * (pw / 2) * (pw / 2);
+    pl.tw = go_tile_edge(out_w / 2);
+    const uint32_t n_oct_level = 3 * (out_w / 2) * (out_w / 2);
+    const uint32_t units_level = (n_oct_level + GO_UNIT - 1) / GO_UNIT;      // one wave each per run
+    // The matrix form takes whole groups of 16 records (inputs of 64 x 64 and more).  It cannot drop
+    // single records after their cosine as EARLY does at wide lobes, and is still the faster one there
+    // (2048 -> 256: 323 ms against 462; 512 -> 64: 1.64 against 2.16).
+    pl.matrix = tuning().ggx_matrix != 0 && (ps * ps) % GO_MX_GROUP == 0;
+    const size_t rec_each = pl.matrix ? (size_t)GO_MX_REC_BYTES : GO_REC * sizeof(float4);
+    ggx_plan_runs(pl, n_oct_level, units_level, 8, GO_SUMS, rec_each, n_units);
     // (the counting variant walks the vector form's records: room for the larger of the two)
     // Matrix form with marked patch octets (ggx_oct_mark_patches): the matrix form's records, then room for
     // the vector form's, of which only the marked patch octets' are written and read.

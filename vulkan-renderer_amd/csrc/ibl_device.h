@@ -192,6 +192,59 @@ __host__ __device__ inline bool octet_unit_in_range(uint32_t u, uint32_t unit, u
     return false;
 }
 
+// ---- hexadecets -----------------------------------------------------------------
+// The same grids are also closed under the exchange of x and y (faces +-X <-> +-Y, the Z faces
+// transposed): an octet and its image under the exchange form a "hexadecet" of 16 texels (8 where the
+// octet is its own image, on the diagonal of the Z faces).  Canonical hexadecets: every octet of the +-X
+// faces, and the octets (j, i) with i <= j of the +-Z faces.  ggx_hex.hip works on them.
+constexpr uint32_t GH_UNIT = 64;            // output hexadecets per wave: one tile
+constexpr uint32_t GH_TILE = 8;             // edge of that tile in canonical positions
+
+// q = row (row + 1) / 2 + col, col <= row
+__host__ __device__ inline void tri_decode(uint32_t q, uint32_t& row, uint32_t& col) {
+    uint32_t r = (uint32_t)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > q) r--;
+    while ((r + 1) * (r + 2) / 2 <= q) r++;
+    row = r;
+    col = q - r * (r + 1) / 2;
+}
+
+// The canonical octet (axis 0: +-X faces, 2: +-Z faces; row j, column i of its member with all components
+// positive) behind lane `lane` of output unit `unit`.  valid: the lane is a hexadecet of the cube (lanes
+// above the diagonal of a diagonal Z tile are not); diagonal: it is its own partner.
+struct HexLane { uint32_t axis, j, i; bool valid, diagonal; };
+__host__ __device__ inline HexLane hex_unit_lane(uint32_t unit, uint32_t lane, uint32_t hw) {
+    const uint32_t t = hw / GH_TILE;
+    HexLane h;
+    uint32_t tj, ti;
+    if (unit < t * t) { h.axis = 0; tj = unit / t; ti = unit - tj * t; }
+    else { h.axis = 2; tri_decode(unit - t * t, tj, ti); }
+    h.j = tj * GH_TILE + lane / GH_TILE;
+    h.i = ti * GH_TILE + lane % GH_TILE;
+    h.valid = h.axis == 0 || h.i <= h.j;
+    h.diagonal = h.axis == 2 && h.i == h.j;
+    return h;
+}
+__host__ __device__ inline uint32_t hex_units_total(uint32_t out_w) {
+    const uint32_t t = (out_w / 2) / GH_TILE;
+    return t * t + t * (t + 1) / 2;
+}
+// Member m of the hexadecet of canonical octet (axis, j, i): bits 0-2 the sign flips, bit 3 the exchange.
+__host__ __device__ inline Texel hex_member(uint32_t axis, uint32_t j, uint32_t i, uint32_t m, uint32_t w) {
+    if (m & 8u) return octet_member(axis == 0 ? 1u : 2u, i, j, m & 7u, w, w);
+    return octet_member(axis, j, i, m & 7u, w, w);
+}
+// Patch hexadecet ph of a patch grid with hpw patch octets per axis and row.
+__host__ __device__ inline void hex_patch_decode(uint32_t ph, uint32_t hpw, uint32_t& axis, uint32_t& pj, uint32_t& pi) {
+    if (ph < hpw * hpw) { axis = 0; pj = ph / hpw; pi = ph - pj * hpw; }
+    else { axis = 2; tri_decode(ph - hpw * hpw, pj, pi); }
+}
+__host__ __device__ inline uint32_t hex_patches_total(uint32_t pw) {
+    const uint32_t hpw = pw / 2;
+    return hpw * hpw + hpw * (hpw + 1) / 2;
+}
+__host__ __device__ inline uint32_t hex_swapbits(uint32_t t) { return (t & 4u) | ((t & 1u) << 1) | ((t >> 1) & 1u); }
+
 // v_add_f32 / v_sub_f32 with the clamp output modifier (result clamped to [0, 1]).
 __device__ __forceinline__ float add_clamp01(float a, float b) {
     return __builtin_amdgcn_fmed3f(a + b, 0.0f, 1.0f);

@@ -25,6 +25,7 @@ struct Tuning {
     int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
     int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
+    int ggx_hex = 1;               // ... through the 16-fold symmetry where the sizes allow (ggx_hex.hip; 0: octets)
     int ggx_rsq = 1;               // ... its weights at narrow lobes through one v_rsq_f32: 1 for inputs from 1024 x 1024, 2 always, 0 never
     float ggx_few = 16.0f;         // ... patches whose radiance amounts to fewer equal texels than this go to the vector pipe (0: none do)
     double ggx_sums_mib = 0.0;     // octet GGX kernel: memory a level's sums may take, in MiB (0: 4096); tests use it to reach the plans of huge levels on small ones
@@ -124,6 +125,7 @@ hipError_t ggx_launch(const GgxPlan& pl, const float* d_env, uint32_t in_w, uint
 // Mirror-octet form of the GGX level (ggx_octets.hip).
 constexpr uint32_t GGX_OCT_UNIT = 64;   // output octets per wave: the unit of sharding
 struct GgxOctPlan {
+    bool hex;                 // the plan of the 16-fold kernel (ggx_hex.hip): units of 64 hexadecets, patch hexadecets, 50 sums
     GgxLevel lv;
     uint32_t n_po;            // patch octets: 3 * (pw/2)^2
     uint32_t tw;              // edge of the output tile used for octet numbering
@@ -141,6 +143,8 @@ struct GgxOctPlan {
     size_t rec_bytes;         // mx_bytes + 7 float4 per input texel octet (vector form; with marks: room for both)
     size_t pn_bytes;          // float4 per patch octet + one for the count of marked ones
 };
+void ggx_plan_runs(GgxOctPlan& pl, uint32_t lanes_level, uint32_t units_level, uint32_t members, uint32_t sums,
+                   size_t rec_each, uint32_t n_units);
 bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
 uint32_t ggx_oct_tile_edge(uint32_t out_w);
 // The call covers the n_units 64-octet units d_units[0], d_units[1], ... (tile-major octet order).
@@ -150,8 +154,21 @@ hipError_t ggx_oct_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
                           float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
                           hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
+// The same level through the cube's 16-fold symmetry (ggx_hex.hip: sign flips and the exchange of x and
+// y): hexadecets of texels in place of octets, matrix form only.  Needs out_w % 16 == 0 on top of what the
+// octet kernel needs.  The plan is a GgxOctPlan with hex set; units are 8 x 8 tiles of canonical positions
+// (the +-X faces' first, then the lower triangle of the +-Z faces').
+bool ggx_hex_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
+uint32_t ggx_hex_units_total(uint32_t out_w);
+uint32_t ggx_hex_units_in_range_count(uint32_t out_w, uint32_t begin, uint32_t count);
+hipError_t ggx_hex_units_in_range_launch(uint32_t out_w, uint32_t begin, uint32_t count, uint32_t* d_list, hipStream_t stream);
+GgxOctPlan ggx_hex_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mips, uint32_t n_units);
+hipError_t ggx_hex_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_w,
+                          const uint32_t* d_units, uint32_t out_begin, uint32_t out_count,
+                          float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
+                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 // The partition of a cube's output texels into shards (sharding.hip).
-enum ShardPartition { SHARD_RANGE = 0, SHARD_LAMB_OCT = 1, SHARD_GGX_OCT = 2 };
+enum ShardPartition { SHARD_RANGE = 0, SHARD_LAMB_OCT = 1, SHARD_GGX_OCT = 2, SHARD_GGX_HEX = 3 };
 struct ShardMap {
     uint32_t partition;   // ShardPartition
     uint32_t out_w;       // face edge of the cube

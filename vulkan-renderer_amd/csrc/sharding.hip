@@ -9,6 +9,8 @@
 //   GGX_OCT   every n_shards-th unit of 64 octets of the tile-major order
 //                                                                 (GGX octet kernel: cost per
 //                                                                 unit varies over the cube)
+//   GGX_HEX   every n_shards-th unit of 64 hexadecets (16 texels each; lanes and members that
+//             do not exist are padding)                           (GGX 16-fold kernel)
 // A shard is a list of `per` slots (the same number for every shard, so that the packed
 // buffers of all shards have one size); a slot names a texel or is padding.
 #include "ibl_device.h"
@@ -25,6 +27,8 @@ uint32_t shard_slots(const ShardMap& m) {
             const uint32_t n_units = (n_oct + GGX_OCT_UNIT - 1) / GGX_OCT_UNIT;
             return (n_units + m.n_shards - 1) / m.n_shards * GGX_OCT_UNIT * 8;
         }
+        case SHARD_GGX_HEX:
+            return (hex_units_total(m.out_w) + m.n_shards - 1) / m.n_shards * GH_UNIT * 16;
         default: return (n_out + m.n_shards - 1) / m.n_shards;
     }
 }
@@ -34,6 +38,15 @@ __host__ __device__ inline uint32_t shard_slot_texel(const ShardMap& m, uint32_t
     const uint32_t w = m.out_w, hw = w / 2;
     const uint32_t n_out = 6 * w * w, n_oct = 3 * hw * hw;
     if (slot >= per) return 0xffffffffu;
+    if (m.partition == SHARD_GGX_HEX) {
+        const uint32_t unit = shard + (slot / (GH_UNIT * 16)) * m.n_shards;
+        if (unit >= hex_units_total(w)) return 0xffffffffu;
+        const HexLane h = hex_unit_lane(unit, (slot / 16) % GH_UNIT, hw);
+        const uint32_t mem = slot % 16;
+        if (!h.valid || (h.diagonal && mem >= 8u)) return 0xffffffffu;
+        Texel t = hex_member(h.axis, h.j, h.i, mem, w);
+        return (t.face * w + t.y) * w + t.x;
+    }
     uint32_t oct;
     if (m.partition == SHARD_LAMB_OCT) {
         const uint32_t per_oct = per / 8;
