@@ -27,17 +27,21 @@ GGX_TIGHT = 3e-5
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(params=["octets", "octets-vector", "general"])
+@pytest.fixture(params=["octets", "octets-matrix", "octets-vector", "general"])
 def kernel_mode(request, ibl):
-    """The implementations of the integrals: the mirror-octet kernels (default where the face sizes
-    allow; their GGX sums go through the matrix pipe as bf16 pieces for inputs of 64 x 64 and more),
-    the same with the GGX sums on the vector pipe in FP32 (ibl_set_tuning("ggx_matrix", 0)), and
-    the general kernels (ibl_set_kernel_mode(1))."""
+    """The implementations of the integrals: the mirror-symmetry kernels as they are chosen by default
+    (GGX: the 16-fold kernel where the output faces are a multiple of 16 wide, the octet kernel
+    elsewhere, sums through the matrix pipe as bf16 pieces for inputs of 64 x 64 and more), the octet
+    kernel's matrix form everywhere (ibl_set_tuning("ggx_hex", 0)), the octet kernel with the GGX sums
+    on the vector pipe in FP32 (ibl_set_tuning("ggx_matrix", 0)), and the general kernels
+    (ibl_set_kernel_mode(1))."""
     ibl.set_kernel_mode(request.param == "general")
     ibl.set_tuning("ggx_matrix", 0 if request.param == "octets-vector" else 1)
+    ibl.set_tuning("ggx_hex", 0 if request.param == "octets-matrix" else 1)
     yield request.param
     ibl.set_kernel_mode(False)
     ibl.set_tuning("ggx_matrix", 1)
+    ibl.set_tuning("ggx_hex", 1)
 
 
 @pytest.fixture(params=["split", "exact", "general"])
@@ -441,6 +445,54 @@ def test_ggx_counts_match_oracle(ibl, orc, kernel_mode):
             assert abs(got["accepted"] - want["accepted"]) <= 1e-4 * want["accepted"] + 8
     finally:
         ibl.set_counting(False)
+
+
+def test_ggx_sixteen_fold_kernel_is_the_one_that_runs(ibl, orc):
+    """Where the output faces are a multiple of 16 wide the GGX level goes through the cube's 16-fold
+    symmetry (sign flips and the exchange of x and y): the counts of texel tests stay the reference's
+    (the octet kernel's counting variant), the records the wavefronts walk halve -- one weight serves 16
+    texel pairs instead of 8 -- and the texels agree with the octet kernel's matrix form to the rounding
+    of FP32 sums, on the diagonals of the Z faces (hexadecets of 8 texels) as everywhere else."""
+    env, env_d = _env(ibl, orc, 128, seed=17)
+    try:
+        res = {}
+        for hex_on in (1, 0):
+            ibl.set_tuning("ggx_hex", hex_on)
+            assert ibl.get_tuning("ggx_hex") == hex_on
+            ibl.set_counting(True)
+            out = ibl.ggx_level(env_d, 64, 1, 3)
+            c = ibl.last_counts()
+            ibl.set_counting(False)
+            res[hex_on] = (ibl.ggx_level(env_d, 64, 1, 3), c)
+            if hex_on:      # (the octet kernel's counting variant is a vector-form kernel of its own)
+                assert ibl.torch.equal(out, res[hex_on][0])          # counting changes no texel of the 16-fold kernel
+        (a, ca), (b, cb) = res[1], res[0]
+        assert ca["tested"] == cb["tested"] and ca["accepted"] == cb["accepted"] and ca["patch_tests"] == cb["patch_tests"]
+        assert 0.4 * cb["wave_records"] < ca["wave_records"] < 0.62 * cb["wave_records"], (ca, cb)
+        rel = ((a - b).abs() / b.abs().clamp_min(1e-30))[..., :3]
+        assert float(rel.max()) < 2e-6
+        diag = ibl.torch.arange(64, device=a.device)
+        for face in (4, 5):                                              # +-Z: both diagonals
+            assert float(rel[face, diag, diag].max()) < 2e-6 and float(rel[face, diag, 63 - diag].max()) < 2e-6
+            assert float(a[face, diag, diag, :3].min()) > 0.0
+        want = orc.ggx_level(env, 64, 64, 1, 3)
+        _check_cube(orc, a.cpu().numpy(), want, tight=GGX_TIGHT, label="16-fold kernel, 128 -> 64")
+        # a 16 x 16 output face stays with the octet kernel (too few units), 24 x 24 is no multiple of 16
+        ibl.set_tuning("ggx_hex", 1)
+        for w, ow, m, mips in ((128, 16, 3, 3), (96, 24, 2, 2)):
+            e, e_d = _env(ibl, orc, w, seed=18)
+            ibl.set_counting(True)
+            ibl.ggx_level(e_d, ow, m, mips)
+            c1 = ibl.last_counts()
+            ibl.set_tuning("ggx_hex", 0)
+            ibl.ggx_level(e_d, ow, m, mips)
+            c0 = ibl.last_counts()
+            ibl.set_counting(False)
+            ibl.set_tuning("ggx_hex", 1)
+            assert c1["wave_records"] == c0["wave_records"]
+    finally:
+        ibl.set_counting(False)
+        ibl.set_tuning("ggx_hex", 1)
 
 
 def test_ggx_512_subset_16x16_patches(ibl, orc, kernel_mode):

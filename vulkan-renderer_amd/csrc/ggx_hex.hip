@@ -499,56 +499,92 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
                         m1 = go_pack_bf16(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u));
                     }
                 };
-                go_dir_load(da, dp);
-                for (uint32_t g = 0; g < w_count; g += GO_MX_GROUP) {
+                // A group of 16 records: the A operands are their weights' pieces (rows = output hexadecets, so the
+                // upper lanes' records 0-7 and the lower lanes' records 8-15 change places), the B operands the
+                // group's record columns, two tiles.
+                struct Pieces { go_u32x4 a0h, a1h, a0m, a1m, a0l, a1l; };
+                struct Columns { go_u32x4 hi[2], mid[2], lo[2]; };
+                auto columns = [&](const go_u32x4* __restrict__ tg) __attribute__((always_inline)) {
+                    Columns c;
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        c.hi[t] = tg[t * 64];
+                        c.mid[t] = tg[128 + t * 64];
+                        if constexpr (EXACT) c.lo[t] = tg[256 + t * 64];
+                    }
+                    return c;
+                };
+                // quarter q of a group's matrix instructions (small terms first)
+                auto products = [&](const Pieces& pc, const Columns& c, int q) __attribute__((always_inline)) {
+                    auto bf = [](const go_u32x4& v) { return __builtin_bit_cast(go_bf16x8, v); };
+                    auto mm = [&](const go_u32x4& a0, const go_u32x4& a1, const go_u32x4& bb, int t) __attribute__((always_inline)) {
+                        mx[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0), bf(bb), mx[t][0], 0, 0, 0);
+                        mx[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(bb), mx[t][1], 0, 0, 0);
+                    };
+                    if constexpr (EXACT) {
+                        // 24 instructions: quarter q takes tile q / 2, and of its six terms the first or the last three
+                        const int t = q / 2;
+                        if (q % 2 == 0) { mm(pc.a0l, pc.a1l, c.hi[t], t); mm(pc.a0h, pc.a1h, c.lo[t], t); mm(pc.a0m, pc.a1m, c.mid[t], t); }
+                        else { mm(pc.a0m, pc.a1m, c.hi[t], t); mm(pc.a0h, pc.a1h, c.mid[t], t); mm(pc.a0h, pc.a1h, c.hi[t], t); }
+                    } else {
+                        // 12 instructions, 3 per quarter: (term, tile) pairs in the order m.hi, h.mid, h.hi per tile
+                        switch (q) {
+                            case 0: mm(pc.a0m, pc.a1m, c.hi[0], 0); mx[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(pc.a0h), bf(c.mid[0]), mx[0][0], 0, 0, 0); break;
+                            case 1: mx[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(pc.a1h), bf(c.mid[0]), mx[0][1], 0, 0, 0); mm(pc.a0h, pc.a1h, c.hi[0], 0); break;
+                            case 2: mm(pc.a0m, pc.a1m, c.hi[1], 1); mx[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(pc.a0h), bf(c.mid[1]), mx[1][0], 0, 0, 0); break;
+                            default: mx[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(pc.a1h), bf(c.mid[1]), mx[1][1], 0, 0, 0); mm(pc.a0h, pc.a1h, c.hi[1], 1); break;
+                        }
+                    }
+                };
+                // The weights of group g, and between them -- four records at a time -- the matrix instructions of the
+                // group before (WITH): a wave issues in order, and a group's matrix instructions in a row at its end
+                // keep the wave off the vector port for 384 cycles that the one other wave of the SIMD cannot fill.
+                // (The statements with the scalar loads and their waits are fixed points of the compiler's schedule,
+                // so the place of the matrix instructions in the source is their place in the code.)
+                auto weights = [&](uint32_t g, auto with_c, const Pieces& before, const Columns& cols) __attribute__((always_inline)) {
+                    constexpr bool WITH = decltype(with_c)::value;
                     uint32_t ah[8], am[8], al[8];
                     go_dir_wait(da);
                     go_dir_load(db, dp + g + 4);
                     quad(da, ah[0], ah[1], am[0], am[1], al[0], al[1]);
+                    if constexpr (WITH) products(before, cols, 0);
                     go_dir_wait(db);
                     go_dir_load(da, dp + g + 8);
                     quad(db, ah[2], ah[3], am[2], am[3], al[2], al[3]);
+                    if constexpr (WITH) products(before, cols, 1);
                     go_dir_wait(da);
                     go_dir_load(db, dp + g + 12);
                     quad(da, ah[4], ah[5], am[4], am[5], al[4], al[5]);
+                    if constexpr (WITH) products(before, cols, 2);
                     go_dir_wait(db);
                     go_dir_load(da, dp + min(g + 16, w_count - 4));
                     quad(db, ah[6], ah[7], am[6], am[7], al[6], al[7]);
-                    // A operands: rows are the output hexadecets, so the upper lanes' records 0-7 and the lower
-                    // lanes' records 8-15 change places
-                    go_u32x4 a0h, a1h, a0m, a1m, a0l, a1l;
+                    if constexpr (WITH) products(before, cols, 3);
+                    Pieces pc;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         auto sh = __builtin_amdgcn_permlane32_swap(ah[i], ah[4 + i], false, false);
-                        a0h[i] = sh[0]; a1h[i] = sh[1];
+                        pc.a0h[i] = sh[0]; pc.a1h[i] = sh[1];
                         auto sm = __builtin_amdgcn_permlane32_swap(am[i], am[4 + i], false, false);
-                        a0m[i] = sm[0]; a1m[i] = sm[1];
+                        pc.a0m[i] = sm[0]; pc.a1m[i] = sm[1];
                         if constexpr (EXACT) {
                             auto sl = __builtin_amdgcn_permlane32_swap(al[i], al[4 + i], false, false);
-                            a0l[i] = sl[0]; a1l[i] = sl[1];
+                            pc.a0l[i] = sl[0]; pc.a1l[i] = sl[1];
                         }
                     }
-                    auto bf = [](const go_u32x4& v) { return __builtin_bit_cast(go_bf16x8, v); };
-#pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        const go_u32x4 b_hi = tp[t * 64], b_mid = tp[128 + t * 64];
-                        if constexpr (EXACT) {
-                            const go_u32x4 b_lo = tp[256 + t * 64];
-                            mx[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0l), bf(b_hi), mx[t][0], 0, 0, 0);
-                            mx[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1l), bf(b_hi), mx[t][1], 0, 0, 0);
-                            mx[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_lo), mx[t][0], 0, 0, 0);
-                            mx[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_lo), mx[t][1], 0, 0, 0);
-                            mx[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0m), bf(b_mid), mx[t][0], 0, 0, 0);
-                            mx[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1m), bf(b_mid), mx[t][1], 0, 0, 0);
-                        }
-                        mx[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0m), bf(b_hi), mx[t][0], 0, 0, 0);
-                        mx[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1m), bf(b_hi), mx[t][1], 0, 0, 0);
-                        mx[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_mid), mx[t][0], 0, 0, 0);
-                        mx[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_mid), mx[t][1], 0, 0, 0);
-                        mx[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a0h), bf(b_hi), mx[t][0], 0, 0, 0);
-                        mx[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1h), bf(b_hi), mx[t][1], 0, 0, 0);
-                    }
+                    return pc;
+                };
+                go_dir_load(da, dp);
+                Pieces cur = weights(0, std::false_type{}, Pieces{}, Columns{});
+                for (uint32_t g = GO_MX_GROUP; g < w_count; g += GO_MX_GROUP) {
+                    const Columns cols = columns(tp);
                     tp += GH_GROUP_WORDS;
+                    cur = weights(g, std::true_type{}, cur, cols);
+                }
+                {
+                    const Columns cols = columns(tp);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) products(cur, cols, q);
                 }
                 go_dir_wait(da);       // nothing of this walk is in flight when it ends
             };
