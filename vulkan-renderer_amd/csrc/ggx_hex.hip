@@ -39,6 +39,11 @@
 
 namespace ibl {
 
+// Records per item of the launch that walks the marked patches: a whole patch.  (The octet kernel's vector
+// walk waits out a scalar load per record when it is alone on its SIMD and is dealt 64 records at a time;
+// this kernel's walk is pipelined, and what a wave pays per item is its set-up, so fewer, longer items:
+// with 64 records the launch took 208 us per level of the 512 chain.)
+constexpr uint32_t GH_MARK_PART = 256;
 constexpr int GH_SUMS = 50;                 // 16 members x RGB, then the weight sums of the two cosets
 constexpr uint32_t GH_GROUP_WORDS = 6 * 64; // 16-byte words per group of 16 records: (upper, middle, lower piece) x 2 tiles x 64 lanes
 constexpr uint32_t GH_REC_BYTES = 16 + GH_GROUP_WORDS * 16 / GO_MX_GROUP;   // direction + its share of a group's tiles
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
         wv = blockIdx.x % n_units;
     }
     const uint32_t run = run_base + run_local;
-    const uint32_t mark_parts = (ps2 + GO_MARK_PART - 1) / GO_MARK_PART;
+    const uint32_t mark_parts = (ps2 + GH_MARK_PART - 1) / GH_MARK_PART;
     // The bounding cones of the call's units (axis, cosine of the widest angle a candidate may have), behind
     // the list of marked patches: the launch that leaves the marked patches out stores them, the launch
     // that walks the marked ones reads them (cones the first did not store are not-a-number: nothing passes).
@@ -287,13 +292,14 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
         const float4 cone = cones[wv];
         const uint32_t* __restrict__ list = (const uint32_t*)(pn + n_ph + 1);
         bool any = false;
-        for (uint32_t it = run; it < n_items; it += n_runs) {
+        for (uint32_t it = run + lane * n_runs; it < n_items && !any; it += 64u * n_runs) {      // 64 items at a time, one per lane
             const uint32_t pt = it / mark_parts;
             const float4 c4 = pn[list[pt >> 4]];
             const uint32_t p = pt & 15u;
             const float x = (p & 1u) ? -c4.x : c4.x, y = (p & 2u) ? -c4.y : c4.y, z = (p & 4u) ? -c4.z : c4.z;
-            any = any || (((p & 8u) ? y : x) * cone.x + ((p & 8u) ? x : y) * cone.y + z * cone.z >= cone.w);
+            any = ((p & 8u) ? y : x) * cone.x + ((p & 8u) ? x : y) * cone.y + z * cone.z >= cone.w;
         }
+        any = __any(any);
         if (!any) return;
     }
     const uint32_t lo = wv * GH_UNIT + lane;
@@ -504,15 +510,10 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
                 // group's record columns, two tiles.
                 struct Pieces { go_u32x4 a0h, a1h, a0m, a1m, a0l, a1l; };
                 struct Columns { go_u32x4 hi[2], mid[2], lo[2]; };
-                auto columns = [&](const go_u32x4* __restrict__ tg) __attribute__((always_inline)) {
-                    Columns c;
-#pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        c.hi[t] = tg[t * 64];
-                        c.mid[t] = tg[128 + t * 64];
-                        if constexpr (EXACT) c.lo[t] = tg[256 + t * 64];
-                    }
-                    return c;
+                auto column = [&](Columns& c, const go_u32x4* __restrict__ tg, int t) __attribute__((always_inline)) {
+                    c.hi[t] = tg[t * 64];
+                    c.mid[t] = tg[128 + t * 64];
+                    if constexpr (EXACT) c.lo[t] = tg[256 + t * 64];
                 };
                 // quarter q of a group's matrix instructions (small terms first)
                 auto products = [&](const Pieces& pc, const Columns& c, int q) __attribute__((always_inline)) {
@@ -541,9 +542,11 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
                 // keep the wave off the vector port for 384 cycles that the one other wave of the SIMD cannot fill.
                 // (The statements with the scalar loads and their waits are fixed points of the compiler's schedule,
                 // so the place of the matrix instructions in the source is their place in the code.)
-                auto weights = [&](uint32_t g, auto with_c, const Pieces& before, const Columns& cols) __attribute__((always_inline)) {
+                auto weights = [&](uint32_t g, auto with_c, const Pieces& before, const go_u32x4* __restrict__ tg) __attribute__((always_inline)) {
                     constexpr bool WITH = decltype(with_c)::value;
                     uint32_t ah[8], am[8], al[8];
+                    Columns cols;
+                    if constexpr (WITH) column(cols, tg, 0);      // (the second tile's columns are fetched halfway: 8 registers)
                     go_dir_wait(da);
                     go_dir_load(db, dp + g + 4);
                     quad(da, ah[0], ah[1], am[0], am[1], al[0], al[1]);
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
                     go_dir_wait(db);
                     go_dir_load(da, dp + g + 8);
                     quad(db, ah[2], ah[3], am[2], am[3], al[2], al[3]);
-                    if constexpr (WITH) products(before, cols, 1);
+                    if constexpr (WITH) { column(cols, tg, 1); products(before, cols, 1); }
                     go_dir_wait(da);
                     go_dir_load(db, dp + g + 12);
                     quad(da, ah[4], ah[5], am[4], am[5], al[4], al[5]);
@@ -575,16 +578,39 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
                     return pc;
                 };
                 go_dir_load(da, dp);
-                Pieces cur = weights(0, std::false_type{}, Pieces{}, Columns{});
-                for (uint32_t g = GO_MX_GROUP; g < w_count; g += GO_MX_GROUP) {
-                    const Columns cols = columns(tp);
-                    tp += GH_GROUP_WORDS;
-                    cur = weights(g, std::true_type{}, cur, cols);
-                }
-                {
-                    const Columns cols = columns(tp);
+                // (two groups per turn, the pieces in two sets that change roles: one set and a copy per group
+                // is 15 moves per group, and the compiler declines to unroll a loop with the scalar loads in it)
+                auto finish = [&](const Pieces& last) __attribute__((always_inline)) {
+                    Columns cols;
+                    column(cols, tp, 0);
+                    column(cols, tp, 1);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) products(cur, cols, q);
+                    for (int q = 0; q < 4; q++) products(last, cols, q);
+                };
+                if constexpr (EXACT) {
+                    // (twice the matrix instructions and a third set of pieces: no room for two groups at once, and
+                    // the matrix pipe is the bound here anyway)
+                    for (uint32_t g = 0; g < w_count; g += GO_MX_GROUP) {
+                        const Pieces pc = weights(g, std::false_type{}, Pieces{}, tp);
+                        finish(pc);
+                        tp += GH_GROUP_WORDS;
+                    }
+                    go_dir_wait(da);
+                    return;
+                }
+                Pieces pa = weights(0, std::false_type{}, Pieces{}, tp);
+                uint32_t g = GO_MX_GROUP;
+                for (; g + GO_MX_GROUP < w_count; g += 2 * GO_MX_GROUP) {
+                    const Pieces pb = weights(g, std::true_type{}, pa, tp);
+                    pa = weights(g + GO_MX_GROUP, std::true_type{}, pb, tp + GH_GROUP_WORDS);
+                    tp += 2 * GH_GROUP_WORDS;
+                }
+                if (g < w_count) {          // an even number of groups: one more before the last one's products
+                    const Pieces pb = weights(g, std::true_type{}, pa, tp);
+                    tp += GH_GROUP_WORDS;
+                    finish(pb);
+                } else {
+                    finish(pa);
                 }
                 go_dir_wait(da);       // nothing of this walk is in flight when it ends
             };
@@ -594,18 +620,31 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
     };
 
     if constexpr (MARKS == 2) {
+        // This run's items -- run, run + n_runs, ... -- 64 at a time, one per lane, as the other launches scan patches
         const uint32_t* __restrict__ list = (const uint32_t*)(pn + n_ph + 1);
         const uint32_t n_items = 16u * mark_parts * __float_as_uint(pn[n_ph].x);
-        for (uint32_t it = run; it < n_items; it += n_runs) {
-            const uint32_t part = it % mark_parts, pt = it / mark_parts;
-            const uint32_t ph = list[pt >> 4], p = pt & 15u;
-            w_begin = part * GO_MARK_PART;
-            w_count = min(ps2 - w_begin, (uint32_t)GO_MARK_PART);
-            const float4 c4 = pn[ph];
-            const float x = (p & 1u) ? -c4.x : c4.x, y = (p & 2u) ? -c4.y : c4.y, z = (p & 4u) ? -c4.z : c4.z;
-            const float dsum = ((p & 8u) ? y : x) * axx + ((p & 8u) ? x : y) * axy + z * axz;
-            if (!(dsum >= wave_thr)) continue;
-            visit(ph, (1u << p) | (dsum >= core_cos ? (65536u << p) : 0u));
+        for (uint32_t first = run; first < n_items; first += 64u * n_runs) {
+            const uint32_t it = first + lane * n_runs;
+            uint32_t ph_v = 0, code = 0;          // code: pattern | stretch << 4 | near the core << 31 | candidate << 30
+            if (it < n_items) {
+                const uint32_t part = it % mark_parts, pt = it / mark_parts;
+                ph_v = list[pt >> 4];
+                const uint32_t p = pt & 15u;
+                const float4 c4 = pn[ph_v];
+                const float x = (p & 1u) ? -c4.x : c4.x, y = (p & 2u) ? -c4.y : c4.y, z = (p & 4u) ? -c4.z : c4.z;
+                const float dsum = ((p & 8u) ? y : x) * axx + ((p & 8u) ? x : y) * axy + z * axz;
+                code = p | (part << 4) | (dsum >= core_cos ? 0x80000000u : 0u) | (dsum >= wave_thr ? 0x40000000u : 0u);
+            }
+            unsigned long long bal = __ballot((code & 0x40000000u) != 0u);
+            while (bal) {                                  // ascending item order
+                const int src = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                const uint32_t ph = __builtin_amdgcn_readlane(ph_v, src), cd = __builtin_amdgcn_readlane(code, src);
+                const uint32_t p = cd & 15u;
+                w_begin = ((cd >> 4) & 0xffffu) * GH_MARK_PART;
+                w_count = min(ps2 - w_begin, GH_MARK_PART);
+                visit(ph, (1u << p) | ((cd >> 31) ? (65536u << p) : 0u));
+            }
         }
     } else {
         // The level's patch hexadecets are dealt round-robin to the runs (run r owns q = r, r + n_runs, ...).
