@@ -287,15 +287,14 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
     if (MARKS == 2) {
         // Before anything per lane: does one of this wave's items (marked patch, pattern, stretch of records)
         // lie inside its unit's cone at all?  With a handful of marked patches nearly every wave leaves here.
-        const uint32_t n_items = 16u * mark_parts * __float_as_uint(pn[n_ph].x);
+        const uint32_t per_pattern = mark_parts * __float_as_uint(pn[n_ph].x), n_items = 16u * per_pattern;
         if (run >= n_items) return;              // fewer items than runs: the sums of this run stand as they are
         const float4 cone = cones[wv];
         const uint32_t* __restrict__ list = (const uint32_t*)(pn + n_ph + 1);
         bool any = false;
         for (uint32_t it = run + lane * n_runs; it < n_items && !any; it += 64u * n_runs) {      // 64 items at a time, one per lane
-            const uint32_t pt = it / mark_parts;
-            const float4 c4 = pn[list[pt >> 4]];
-            const uint32_t p = pt & 15u;
+            const uint32_t p = it / per_pattern;
+            const float4 c4 = pn[list[(it - p * per_pattern) / mark_parts]];
             const float x = (p & 1u) ? -c4.x : c4.x, y = (p & 2u) ? -c4.y : c4.y, z = (p & 4u) ? -c4.z : c4.z;
             any = ((p & 8u) ? y : x) * cone.x + ((p & 8u) ? x : y) * cone.y + z * cone.z >= cone.w;
         }
@@ -620,16 +619,19 @@ __global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs
     };
 
     if constexpr (MARKS == 2) {
-        // This run's items -- run, run + n_runs, ... -- 64 at a time, one per lane, as the other launches scan patches
+        // This run's items -- run, run + n_runs, ... -- 64 at a time, one per lane, as the other launches scan patches.
+        // Items are numbered pattern-major (all stretches of all marked patches under pattern 0, then under
+        // pattern 1, ...): a unit's cone mostly holds patches under one pattern, and with the pattern in the low
+        // bits of the number those would all fall to runs of one residue modulo 8 -- one XCD of the eight.
         const uint32_t* __restrict__ list = (const uint32_t*)(pn + n_ph + 1);
-        const uint32_t n_items = 16u * mark_parts * __float_as_uint(pn[n_ph].x);
+        const uint32_t per_pattern = mark_parts * __float_as_uint(pn[n_ph].x), n_items = 16u * per_pattern;
         for (uint32_t first = run; first < n_items; first += 64u * n_runs) {
             const uint32_t it = first + lane * n_runs;
             uint32_t ph_v = 0, code = 0;          // code: pattern | stretch << 4 | near the core << 31 | candidate << 30
             if (it < n_items) {
-                const uint32_t part = it % mark_parts, pt = it / mark_parts;
-                ph_v = list[pt >> 4];
-                const uint32_t p = pt & 15u;
+                const uint32_t p = it / per_pattern, within = it - p * per_pattern;
+                const uint32_t part = within % mark_parts;
+                ph_v = list[within / mark_parts];
                 const float4 c4 = pn[ph_v];
                 const float x = (p & 1u) ? -c4.x : c4.x, y = (p & 2u) ? -c4.y : c4.y, z = (p & 4u) ? -c4.z : c4.z;
                 const float dsum = ((p & 8u) ? y : x) * axx + ((p & 8u) ? x : y) * axy + z * axz;

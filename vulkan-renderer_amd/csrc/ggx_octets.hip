@@ -664,13 +664,15 @@ __global__ __launch_bounds__(GO_WG, COUNT ? 4 : (MX ? GO_MX_MIN_WAVES : GO_MIN_W
         // The marked patch octets, in ascending order, times the 8 sign patterns times stretches of 64
         // records are dealt to the runs one item at a time: a handful of marked patches -- the usual case --
         // is then one short walk for each of many waves, not eight long ones after each other for a few (a
-        // lone wave waits out the latency of every record it loads).
+        // lone wave waits out the latency of every record it loads).  Items are numbered pattern-major: with
+        // the pattern in the low bits, the patches a unit's cone holds under one pattern would all fall to
+        // runs of one residue modulo 8, which the grid order places on one XCD.
         const uint32_t* __restrict__ list = (const uint32_t*)(pn + n_po + 1);
         const uint32_t parts = (ps2 + GO_MARK_PART - 1) / GO_MARK_PART;
-        const uint32_t n_items = 8u * parts * __float_as_uint(pn[n_po].x);
+        const uint32_t per_pattern = parts * __float_as_uint(pn[n_po].x), n_items = 8u * per_pattern;
         for (uint32_t it = run; it < n_items; it += n_runs) {
-            const uint32_t part = it % parts, pt = it / parts;
-            const uint32_t po = list[pt >> 3], tau = pt & 7u;
+            const uint32_t tau = it / per_pattern, within = it - tau * per_pattern;
+            const uint32_t part = within % parts, po = list[within / parts];
             w_begin = part * GO_MARK_PART;
             w_count = min(ps2 - w_begin, (uint32_t)GO_MARK_PART);
             const float4 c4 = pn[po];
