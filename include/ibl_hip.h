@@ -143,9 +143,14 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
  * factor (16 significant bits; knob "ggx_matrix", 1 by default, 0 keeps them in FP32 on the vector
  * pipe).  The 2^-18 cut of a term is random and averages out over the texels under a lobe; where it
  * could not -- patches whose radiance amounts to fewer than 16 equal texels in some channel (knob
- * "ggx_few"; a sun of a few texels, one lamp on black) -- the patch is walked with FP32 products on
- * the vector pipe instead, by a second launch that adds into the same sums.  Measured against the
- * FP32 form: <= 1e-6, 99.99 % of the RGBE texels identical, lone lights included.  On inputs of
+ * "ggx_few"; a sun of a few texels, one lamp on black) -- the patch is walked by a second launch
+ * that adds into the same sums: with three bf16 pieces of each factor and six partial products
+ * (products exact to 2^-25) at the levels the 16-fold kernel serves, with FP32 products on the
+ * vector pipe at the others.  That kernel evaluates a weight once for the 16 images of a texel pair
+ * under the cube's sign flips and the exchange of x and y, which leave the reference's cosine
+ * unchanged to the bit; it serves outputs of 32 x 32 and more whose width is a multiple of 16 (knob
+ * "ggx_hex", 1 by default; 0: the 8 sign flips only, as at the smaller levels).  Measured against
+ * the FP32 form: <= 1e-6, 99.99 % of the RGBE texels identical, lone lights included.  On inputs of
  * 1024 x 1024 and more, at the levels whose acceptance window ends above the horizon
  * (cutoff > 1/2), that form takes sqrt(NoH^2) / denom^2 of cube.cpp:280-281 as one reciprocal
  * square root (knob "ggx_rsq": 1 this rule, 0 never, 2 at every such level; the two forms agree
@@ -342,7 +347,7 @@ int ibl_set_kernel_mode(int general_only);
 /* Launch-shape knobs of the kernels (slice counts, grid orders; the names are the
  * library's own, the tools under tools/ use them).  They change speed only, except
  * the slice counts, which fix the order of the sums and with it the last bits, and
- * "lamb_split" / "ggx_matrix" / "ggx_few" / "ggx_rsq", which choose between two forms of the arithmetic (see
+ * "lamb_split" / "ggx_matrix" / "ggx_hex" / "ggx_few" / "ggx_rsq", which choose between two forms of the arithmetic (see
  * ibl_lambertian_dev and ibl_ggx_level_dev). */
 int ibl_set_tuning(const char* name, double value);
 /* The current value of a knob ("general_only" reads back ibl_set_kernel_mode). */

@@ -355,6 +355,7 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "ggx_matrix")) g_tuning.ggx_matrix = (int)value;
     else if (!strcmp(name, "ggx_rsq")) g_tuning.ggx_rsq = (int)value;
     else if (!strcmp(name, "ggx_hex")) g_tuning.ggx_hex = (int)value;
+    else if (!strcmp(name, "ggx_wg_waves")) g_tuning.ggx_wg_waves = (int)value;
     else if (!strcmp(name, "ggx_few")) g_tuning.ggx_few = (float)value;
     else if (!strcmp(name, "ggx_sums_mib")) g_tuning.ggx_sums_mib = value;
     else if (!strcmp(name, "bake_rehearse_shards")) g_tuning.bake_rehearse_shards = (int)value;
@@ -379,6 +380,7 @@ int ibl_get_tuning(const char* name, double* value) {
     else if (!strcmp(name, "ggx_matrix")) *value = g_tuning.ggx_matrix;
     else if (!strcmp(name, "ggx_rsq")) *value = g_tuning.ggx_rsq;
     else if (!strcmp(name, "ggx_hex")) *value = g_tuning.ggx_hex;
+    else if (!strcmp(name, "ggx_wg_waves")) *value = g_tuning.ggx_wg_waves;
     else if (!strcmp(name, "ggx_few")) *value = g_tuning.ggx_few;
     else if (!strcmp(name, "ggx_sums_mib")) *value = g_tuning.ggx_sums_mib;
     else if (!strcmp(name, "bake_rehearse_shards")) *value = g_tuning.bake_rehearse_shards;

@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void ggx_hex_prep(const float4* __restrict__ e
 }
 
 // ---- the pair kernel ----------------------------------------------------------------------------------
+#ifndef GH_WG_WAVES
+#define GH_WG_WAVES 4           // most waves a workgroup may have (the launch bound)
+#endif
 #ifndef GH_MIN_WAVES
 #define GH_MIN_WAVES 2          // (3: 168 registers, 23 of them spilled, and 1.5-4 % slower on every level of the 512 and 2048 chains;
 #endif                          //  the run's sums take 13 KB of LDS per wave, so 12 waves would fill a CU's 160 KB anyway)
@@ -254,30 +257,37 @@ __global__ __launch_bounds__(256) void ggx_hex_prep(const float4* __restrict__ e
 // (patch, pattern, stretch of 64 records) items, and the run's sums are ADDED to what the launch before
 // (MARKS = 1, same grid) stored.
 template <bool EXACT, bool NARROW, int MARKS>
-__global__ __launch_bounds__(GO_WG, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs(
+__global__ __launch_bounds__(GO_WG * GH_WG_WAVES, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs(
     const float4* __restrict__ rec, const float4* __restrict__ pn, const uint32_t* __restrict__ units,
     uint32_t n_ph, uint32_t ps2, uint32_t out_w, uint32_t oct_local,
     uint32_t runs_and_order, uint32_t out_begin, uint32_t out_count,
     float cutoff, float a2m1, float cmin, float theta_acc, float core_thr,
     float* __restrict__ partial, unsigned long long* __restrict__ counts) {
-    static_assert(GO_WG == 64, "one wave per workgroup: the grid below is counted in waves");
+    static_assert(GO_WG == 64, "waves are independent: the grid below is counted in groups of GH_WG_WAVES of them");
     static_assert(EXACT == (MARKS == 2), "the exact products are for the marked patches");
-    __shared__ float s_run[GH_SUMS][GO_WG + 1];       // the run's running sums: [sum][lane], rows padded
+    extern __shared__ float s_all[];       // per wave of the workgroup, the run's running sums: [sum][lane], rows padded
+    float (*s_run)[GO_WG + 1] = (float (*)[GO_WG + 1])(s_all + (threadIdx.x >> 6) * (GH_SUMS * (GO_WG + 1)));
+    const uint32_t wg_waves = blockDim.x >> 6;          // 1 ... GH_WG_WAVES
     const uint32_t lane = threadIdx.x & 63;
     // (run count of the level, first run of this launch and the grid order in one argument, as in ggx_oct_pairs)
     const uint32_t n_runs = runs_and_order & 0x7fffu;
     const uint32_t run_base = (runs_and_order >> 15) & 0x7fffu;
     const bool xcd_runs = (runs_and_order >> 31) != 0u;
     const uint32_t n_units = oct_local / GH_UNIT;
+    // A workgroup is a few neighbouring units of one run: its waves share nothing but their compute unit,
+    // where they walk the same patches at about the same time -- their direction blocks and column tiles
+    // then come from the unit's scalar and vector caches instead of the L2 (the launch decides how many).
+    const uint32_t n_ugroups = (n_units + wg_waves - 1) / wg_waves;
     uint32_t run_local, wv;
     if (xcd_runs) {                                                  // XCD k works on runs k, k + 8, ...
         const uint32_t seq = blockIdx.x / 8;
-        run_local = blockIdx.x % 8 + 8 * (seq / n_units);
-        wv = seq % n_units;
+        run_local = blockIdx.x % 8 + 8 * (seq / n_ugroups);
+        wv = (seq % n_ugroups) * wg_waves + (threadIdx.x >> 6);
     } else {
-        run_local = blockIdx.x / n_units;
-        wv = blockIdx.x % n_units;
+        run_local = blockIdx.x / n_ugroups;
+        wv = (blockIdx.x % n_ugroups) * wg_waves + (threadIdx.x >> 6);
     }
+    if (wv >= n_units) return;                                       // (no barrier anywhere: a wave may leave alone)
     const uint32_t run = run_base + run_local;
     const uint32_t mark_parts = (ps2 + GH_MARK_PART - 1) / GH_MARK_PART;
     // The bounding cones of the call's units (axis, cosine of the widest angle a candidate may have), behind
@@ -786,7 +796,12 @@ hipError_t ggx_hex_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
     uint32_t xcd_runs = (pl.runs_per_pass % 8 == 0 &&
                          (pl.out_units < 3072u || 16.0 * cone < 3.0 || run_bytes > (double)(2u << 20))) ? 1u : 0u;
     if (tuning().ggx_xcd_slices >= 0) xcd_runs = (tuning().ggx_xcd_slices != 0 && pl.runs_per_pass % 8 == 0) ? 1u : 0u;
-    const dim3 grid(pl.runs_per_pass * pl.out_units);
+    // (waves per workgroup: 4 neighbouring units from 1024^2 inputs on -- 2 % on the 2048 chain, nothing or a
+    // little less than nothing on the 512 chain, 8 is 8 % slower on both)
+    uint32_t wg_waves = in_w >= 1024u ? GH_WG_WAVES : 1u;
+    if (tuning().ggx_wg_waves >= 1) wg_waves = (uint32_t)tuning().ggx_wg_waves < (uint32_t)GH_WG_WAVES ? (uint32_t)tuning().ggx_wg_waves : (uint32_t)GH_WG_WAVES;
+    const dim3 grid(pl.runs_per_pass * ((pl.out_units + wg_waves - 1) / wg_waves));
+    const size_t lds_bytes = (size_t)wg_waves * GH_SUMS * (GO_WG + 1) * sizeof(float);
     const uint32_t oct_count = pl.out_units * GH_UNIT;
     const uint32_t small_blocks = (oct_count + GO_THREADS - 1) / GO_THREADS;
     double* d_groups = d_partial;
@@ -802,7 +817,7 @@ hipError_t ggx_hex_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
         const uint32_t run_base = pass * pl.runs_per_pass;
         const uint32_t packed = pl.n_runs | (run_base << 15) | (xcd_runs << 31);
         auto go = [&](auto kernel) {
-            kernel<<<grid, GO_WG, 0, stream>>>((const float4*)d_rec, (const float4*)d_pn, d_units, pl.n_po, ps2, out_w,
+            kernel<<<grid, GO_WG * wg_waves, lds_bytes, stream>>>((const float4*)d_rec, (const float4*)d_pn, d_units, pl.n_po, ps2, out_w,
                 oct_count, packed, out_begin, out_count, pl.lv.cutoff, a2m1, cmin, theta_walk, core_thr, d_runs, d_counts);
         };
         if (pl.marks) {

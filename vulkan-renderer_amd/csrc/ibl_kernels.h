@@ -26,6 +26,7 @@ struct Tuning {
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
     int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
     int ggx_hex = 1;               // ... through the 16-fold symmetry where the sizes allow (ggx_hex.hip; 0: octets)
+    int ggx_wg_waves = 0;          // waves (neighbouring units) per workgroup of ggx_hex_pairs: 0 = by input size, 1-4
     int ggx_rsq = 1;               // ... its weights at narrow lobes through one v_rsq_f32: 1 for inputs from 1024 x 1024, 2 always, 0 never
     float ggx_few = 16.0f;         // ... patches whose radiance amounts to fewer equal texels than this go to the vector pipe (0: none do)
     double ggx_sums_mib = 0.0;     // octet GGX kernel: memory a level's sums may take, in MiB (0: 4096); tests use it to reach the plans of huge levels on small ones
