@@ -406,6 +406,8 @@ __global__ __launch_bounds__(GO_WG * GH_WG_WAVES, EXACT ? 2 : GH_MIN_WAVES) void
                 float* q = &s_run[oc][4u * (lane >> 5)];
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
+                    // (read, add, write: the LDS's own add, ds_add_f32, needs no wait but runs at a fraction of
+                    // the rate -- the 2048 chain took 2.11 s with it instead of 1.17)
                     const int row = (i & 3) + 8 * (i >> 2);
                     q[row] += mx[t][0][i];
                     q[32 + row] += mx[t][1][i];
