@@ -427,7 +427,7 @@ def chain_extra(name, args, ibl, rank, world, dist, torch, steps, cpu_seconds):
         out[name + "_level1_frac_of_fp32_peak"] = round(tf / FP32_VECTOR_PEAK_TFLOPS, 4)
         out[name + "_level1_algorithmic_equiv_tflops"] = round(wl.flop_per_launch / (kernel_ms * 1e-3) / 1e12, 2)
         if getattr(wl, "matrix_flop_per_launch", None):
-            # the kernel's time is the sum of its two pipes' shares (measured: they do not overlap on a SIMD)
+            # the two pipes' shares of the kernel's time, and their sum
             mtf = wl.matrix_flop_per_launch / (kernel_ms * 1e-3) / 1e12
             out[name + "_level1_matrix_bf16_tflops"] = round(mtf, 1)
             out[name + "_level1_frac_of_bf16_matrix_peak"] = round(mtf / BF16_MATRIX_PEAK_TFLOPS, 4)
