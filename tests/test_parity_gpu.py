@@ -286,6 +286,39 @@ def test_lambertian_split_falls_back_where_it_cancels(ibl, orc):
     assert rel_err(got.cpu().numpy().reshape(-1, 4), exact.reshape(-1, 4)).max() < 5e-6
 
 
+def test_lambertian_split_has_room_under_its_limit(ibl, orc):
+    """The fast path keeps every octet whose even and odd halves cancel by less than the limit (16).
+    Lights of rising strength put different octets just under that limit; all of them must stay
+    inside the tests' tight bar.  And with the limit out of the way altogether (no octet redone,
+    cancellation up to ~35) the result is still inside the stated bars (1e-3 per texel, 99.9 % of
+    the RGBE texels identical): the limit sits a factor of two and more below where they could fail."""
+    base, _ = _env(ibl, orc, 64)
+    n_oct = 6 * 32 * 32 // 8
+    ibl.set_counting(True)
+    try:
+        seen = []
+        for strength in (1.5e3, 3.0e3, 6.0e3, 1.0e4):
+            env = base.copy()
+            env[0, 20:24, 30:34, :3] = np.float32(strength)
+            got = ibl.lambertian(_dev(ibl, env), 32)
+            seen.append(ibl.last_exact_octets())
+            _check_cube(orc, got.cpu().numpy(), orc.lambertian(env, 32), label="light %g, %d octets redone" % (strength, seen[-1]))
+        assert seen == sorted(seen) and seen[0] < seen[-1] < n_oct, seen      # the limit is crossed by more and more octets
+        ibl.set_tuning("lamb_split_limit", 1e9)
+        try:
+            got = ibl.lambertian(_dev(ibl, env), 32).cpu().numpy()
+            assert ibl.last_exact_octets() == 0
+        finally:
+            ibl.set_tuning("lamb_split_limit", 16)
+        want = orc.lambertian(env, 32)
+        err = rel_err(got.reshape(-1, 4), want.reshape(-1, 4))
+        assert err.max() < 2e-5, err.max()
+        frac = byte_identical_fraction(orc.rgbe_encode(got.reshape(-1, 4)), orc.rgbe_encode(want.reshape(-1, 4)))
+        assert frac >= BYTE_FRACTION, frac          # (measured: 1 texel of 6144 one step off, 4e-6 worst)
+    finally:
+        ibl.set_counting(False)
+
+
 def test_lambertian_large_input_subset(ibl, orc, lamb_mode):
     """1024x1024/face input (the headline Lambertian configuration's input), 256 of its 128x128/face
     output texels against the oracle; the full output is covered by

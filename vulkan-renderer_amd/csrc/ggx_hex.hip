@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256) void ggx_hex_prep(const float4* __restrict__ e
 #define GH_WG_WAVES 4           // most waves a workgroup may have (the launch bound)
 #endif
 #ifndef GH_MIN_WAVES
-#define GH_MIN_WAVES 2          // (3: 168 registers, 23 of them spilled, and 1.5-4 % slower on every level of the 512 and 2048 chains;
-#endif                          //  the run's sums take 13 KB of LDS per wave, so 12 waves would fill a CU's 160 KB anyway)
+#define GH_MIN_WAVES 2          // (3: 168 registers; the plain one-group loop then has one spill in it and is 9 % slower on the 512
+#endif                          //  and 2048 chains -- the SIMDs are busy at 2: vector and matrix instructions' times add up)
 // EXACT: three bf16 pieces per factor and six partial products (marked patches).
 // NARROW: the weight form for windows that end above the horizon (go_weight_quad).
 // MARKS: 0 every patch hexadecet; 1 all but the marked ones; 2 only the marked ones, dealt to the runs as
