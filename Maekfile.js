@@ -102,20 +102,21 @@ const libibl = LINK(kernels, 'libibl_hip.so', { linker: HIPCC, flags: ['--offloa
 
 const host = `${PKG}/host`;
 const png_io = CPP(`${host}/png_io.cpp`, [`${host}/png_io.hpp`]);
+const formats = CPP(`${host}/image_formats.cpp`, [`${host}/png_io.hpp`]);
 const scene = CPP(`${host}/s72_scene.cpp`, [`${host}/s72_scene.hpp`]);
 const cube_o = CPP(`${host}/cube.cpp`, [`${host}/png_io.hpp`, `${host}/s72_scene.hpp`]);
 // With OUT set and no library built there, bin/cube links the one in the tree.
 const treeLib = path.join(ROOT, PKG, 'libibl_hip.so');
 const useTree = process.env.OUT && mtime(treeLib) !== null && process.env.MAEK_LINK_TREE_LIB === '1';
 const libDir = useTree ? path.join(ROOT, PKG) : OUT;
-// bin/cube: the tool, its PNG and scene readers, zlib and the HIP library -- none of the renderer
+// bin/cube: the tool, its image and scene readers, zlib and the HIP library -- none of the renderer
 // (the reference links its tool against every object of the viewer, Maekfile.js:78-83).
-LINK([cube_o, png_io, scene], 'bin/cube', {
+LINK([cube_o, png_io, formats, scene], 'bin/cube', {
     libs: ['-L' + libDir, '-libl_hip', '-lz', '-pthread', '-Wl,-rpath,' + libDir, '-Wl,-rpath,/opt/rocm/lib'],
     deps: [useTree ? treeLib : libibl],
 });
 LINK([CPP(`${host}/png_roundtrip.cpp`, [`${host}/png_io.hpp`]), png_io], 'bin/png_roundtrip', { libs: ['-lz', '-pthread'] });
-LINK([CPP(`${host}/png_capi.cpp`, [`${host}/png_io.hpp`]), png_io], 'libibl_png.so', { flags: ['-shared', '-fPIC'], libs: ['-lz', '-pthread'] });
+LINK([CPP(`${host}/png_capi.cpp`, [`${host}/png_io.hpp`]), png_io, formats], 'libibl_png.so', { flags: ['-shared', '-fPIC'], libs: ['-lz', '-pthread'] });
 
 // ---- command line ------------------------------------------------------------------------------
 const args = process.argv.slice(2);

@@ -132,7 +132,7 @@ void bake_file(const std::filesystem::path& input_path, const BakeOptions& opt) 
     std::vector<uint8_t> pixels;
     std::string err;
     StageClock clock;
-    if (!png_read_rgba8(input_path.string(), w, h, pixels, err)) PANIC("failed to load texture image! (" + err + ")");
+    if (!image_read_rgba8(input_path.string(), w, h, pixels, err)) PANIC("failed to load texture image! (" + err + ")");
     clock.lap("read input PNG");
     h /= 6;
     if (w == 0 || h != w) PANIC("input must be a W x 6W strip of square cube faces");

@@ -23,10 +23,30 @@ def _native():
         lib.ibl_png_read_rgba8.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                            ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_char_p, ctypes.c_size_t]
         lib.ibl_png_read_rgba8.restype = ctypes.c_int
+        lib.ibl_image_read_rgba8.argtypes = lib.ibl_png_read_rgba8.argtypes
+        lib.ibl_image_read_rgba8.restype = ctypes.c_int
         lib.ibl_png_free.argtypes = [ctypes.POINTER(ctypes.c_uint8)]
         lib.ibl_png_free.restype = None
         _lib = lib
     return _lib
+
+
+def read_image(path):
+    """Any input format the cube tool reads (PNG, BMP, binary PGM/PPM, Radiance HDR, TGA; recognised by
+    content and converted to RGBA8 by stb_image's rules, host/image_formats.cpp) -> (H, W, 4) uint8.
+    Needs the native library."""
+    lib = _native()
+    if lib is None:
+        raise RuntimeError("libibl_png.so is not built")
+    w, h = ctypes.c_uint32(), ctypes.c_uint32()
+    px = ctypes.POINTER(ctypes.c_uint8)()
+    err = ctypes.create_string_buffer(256)
+    if lib.ibl_image_read_rgba8(os.fsencode(path), ctypes.byref(w), ctypes.byref(h), ctypes.byref(px), err, 256) != 0:
+        raise ValueError(err.value.decode() or "cannot read %s" % path)
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib.ibl_png_free(px)
 
 
 def read_rgba8(path, native=True):
