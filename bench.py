@@ -51,6 +51,11 @@ LAMB_FLOP_PER_LANE_PATTERN = 49
 # issued (hipcc -S): 2 multiplies and 2 FMAs for a+b, a-b and c (6), max, min, max, median (4),
 # 4 adds, 6 packed FMAs of 2 x 2 flop (24): 38.  No per-pattern part.
 LAMB_SPLIT_FLOP_PER_LANE_RECORD = 38
+# lh_pairs (the default where the sizes allow: the same split over hexadecets, 256 texel pairs per lane
+# and record) as issued (hipcc -S): 2 packed multiplies and a multiply for the products (5), 2 packed
+# adds (4), max, min, max, median for each of the two weight sets (8), 6 packed adds (12), 18 packed
+# FMAs of 2 x 2 flop (72): 101.
+LAMB_HEX_FLOP_PER_LANE_RECORD = 101
 # ggx_oct_pairs per lane, record and pattern: cosine 5 (every record walked); then, for the records
 # evaluated (all of them at narrow lobes; at wide lobes those some lane of the wave accepts):
 # u/t/d 5, rcp + sqrt 2, two clamped ops 2, three multiplies 3, the weight sum's FMA 2 and 12 packed
@@ -138,15 +143,20 @@ class Workload:
             c = ibl.last_counts()
             ibl.set_counting(False)
             self.split = ibl.get_tuning("lamb_split") != 0
+            # (the hexadecet form: even, mirror-exact faces -- every power of two -- with an output of a multiple of 16 >= 32)
+            self.hex = (self.split and ibl.get_tuning("lamb_hex") != 0 and ibl.get_tuning("general_only") == 0
+                        and self.out_w % 16 == 0 and self.out_w >= 32 and self.in_w % 16 == 0 and self.in_w >= 32
+                        and self.in_w & (self.in_w - 1) == 0 and self.out_w & (self.out_w - 1) == 0)
             self.exact_octets = ibl.last_exact_octets() if self.split else None
             if c["wave_records"] and self.split:
-                self.executed_flop_per_launch = 64.0 * LAMB_SPLIT_FLOP_PER_LANE_RECORD * c["wave_records"]
+                self.executed_flop_per_launch = 64.0 * c["wave_records"] * (LAMB_HEX_FLOP_PER_LANE_RECORD if self.hex
+                                                                            else LAMB_SPLIT_FLOP_PER_LANE_RECORD)
                 self.patterns_per_record = None
             elif c["wave_records"]:
                 self.executed_flop_per_launch = 64.0 * (LAMB_FLOP_PER_LANE_RECORD * c["wave_records"]
                                                         + LAMB_FLOP_PER_LANE_PATTERN * c["wave_patterns"])
                 self.patterns_per_record = c["wave_patterns"] / c["wave_records"]
-            self.kernel = "ls_pairs" if self.split else "lambertian_oct_pairs"
+            self.kernel = ("lh_pairs" if self.hex else "ls_pairs") if self.split else "lambertian_oct_pairs"
             self.desc = ("C%s: Lambertian irradiance %dx%d/face -> %dx%d/face, all (output, input) texel pairs"
                          % (name[1], self.in_w, self.in_w, self.out_w, self.out_w))
             self.bytes_per_launch = 24 * self.n_in + 16 * self.count

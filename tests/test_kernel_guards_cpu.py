@@ -54,7 +54,7 @@ def test_checker_sees_a_register_touched_in_flight():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("source", ["ggx_octets.hip", "lambertian_split.hip"])
+@pytest.mark.parametrize("source", ["ggx_octets.hip", "ggx_hex.hip", "lambertian_split.hip", "lambertian_hex.hip"])
 def test_hand_written_scalar_loads_are_left_alone(source):
     lines = check_scalar_loads.assembly(os.path.join(CSRC, source))
     loads = 0
@@ -66,9 +66,10 @@ def test_hand_written_scalar_loads_are_left_alone(source):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("source,kernel", [("ggx_octets.hip", "ggx_oct_pairs"), ("lambertian_split.hip", "ls_pairs")])
+@pytest.mark.parametrize("source,kernel", [("ggx_octets.hip", "ggx_oct_pairs"), ("lambertian_split.hip", "ls_pairs"),
+                                           ("lambertian_hex.hip", "lh_pairs")])
 def test_hot_kernels_have_no_scratch(source, kernel):
-    extra = ["-fno-slp-vectorize"] if source == "lambertian_split.hip" else []
+    extra = ["-fno-slp-vectorize"] if source.startswith("lambertian_") else []
     found = 0
     for k in kernel_resources.resources(os.path.join(CSRC, source), extra):
         if kernel in k["name"]:

@@ -26,11 +26,12 @@ def test_dry_run_lists_every_rule(tmp_path):
     lines = r.stdout.strip().splitlines()
     hip = [l for l in lines if "--offload-arch=gfx950" in l and " -c " in l]
     sources = sorted(f for f in os.listdir(os.path.join(ROOT, "vulkan-renderer_amd", "csrc")) if f.endswith(".hip"))
-    assert len(hip) == len(sources) == 12
+    assert len(hip) == len(sources) == 13
     for s in sources:
         assert any(l.rstrip().split(" -o ")[0].endswith(s) for l in hip), s
     assert any("lambertian_split.hip" in l and "-fno-slp-vectorize" in l for l in hip)
-    assert sum("-fno-slp-vectorize" in l for l in hip) == 1
+    assert any("lambertian_hex.hip" in l and "-fno-slp-vectorize" in l for l in hip)
+    assert sum("-fno-slp-vectorize" in l for l in hip) == 2
     link_lib = [l for l in lines if "-shared" in l and l.split(" -o ")[1].split()[0].endswith("libibl_hip.so")]
     assert len(link_lib) == 1 and link_lib[0].count(".o") >= 11
     cube = [l for l in lines if " -o " in l and l.split(" -o ")[1].split()[0].endswith("bin/cube")]

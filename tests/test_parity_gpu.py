@@ -44,17 +44,21 @@ def kernel_mode(request, ibl):
     ibl.set_tuning("ggx_hex", 1)
 
 
-@pytest.fixture(params=["split", "exact", "general"])
+@pytest.fixture(params=["hex", "split", "exact", "general"])
 def lamb_mode(request, ibl):
-    """The three implementations of the Lambertian integral: mirror octets with the clamped cosine
-    split into its even and odd halves (the default; blocks it cannot hold to ~1e-6 are redone with
-    exact weights), mirror octets with the reference's per-pair weights throughout
-    (ibl_set_tuning("lamb_split", 0)), and the general kernel."""
+    """The four implementations of the Lambertian integral: the clamped cosine split into its even and
+    odd halves over hexadecets -- the 8 sign flips and the exchange of x and y -- (the default where the
+    output is a multiple of 16 wide and at least 32; octets it cannot hold to ~1e-6 are redone with exact
+    weights), the same split over mirror octets (ibl_set_tuning("lamb_hex", 0); the default at the other
+    even sizes), mirror octets with the reference's per-pair weights throughout ("lamb_split" 0), and
+    the general kernel."""
     ibl.set_kernel_mode(request.param == "general")
     ibl.set_tuning("lamb_split", 0 if request.param == "exact" else 1)
+    ibl.set_tuning("lamb_hex", 1 if request.param == "hex" else 0)
     yield request.param
     ibl.set_kernel_mode(False)
     ibl.set_tuning("lamb_split", 1)
+    ibl.set_tuning("lamb_hex", 1)
 
 
 def _dev(ibl, arr):
@@ -210,7 +214,7 @@ def test_downscale_rejects_bad_factor(ibl, orc):
 
 # ---- Lambertian --------------------------------------------------------------------------
 
-@pytest.mark.parametrize("w,out", [(16, 8), (64, 32), (32, 5), (128, 16), (24, 6), (30, 10), (17, 3)])
+@pytest.mark.parametrize("w,out", [(16, 8), (64, 32), (32, 5), (128, 16), (24, 6), (30, 10), (17, 3), (128, 64), (256, 32), (96, 48)])
 def test_lambertian_parity(ibl, orc, w, out, lamb_mode):
     env, env_d = _env(ibl, orc, w)
     got = ibl.lambertian(env_d, out).cpu().numpy()

@@ -174,6 +174,13 @@ __host__ __device__ inline void octet_decode(uint32_t g, uint32_t hw, uint32_t t
     oi = tx * tw + lx;
 }
 
+// The number octet_decode takes apart.
+__host__ __device__ inline uint32_t octet_encode(uint32_t axis, uint32_t oj, uint32_t oi, uint32_t hw, uint32_t tw) {
+    const uint32_t tpr = hw / tw;
+    const uint32_t tile = axis * (tpr * tpr) + (oj / tw) * tpr + oi / tw;
+    return tile * (tw * tw) + (oj % tw) * tw + oi % tw;
+}
+
 // Does unit u (octets u*unit .. u*unit+unit-1 of the tile-major order) hold a texel whose
 // (face, y, x) index lies in [begin, begin + count)?
 __host__ __device__ inline bool octet_unit_in_range(uint32_t u, uint32_t unit, uint32_t hw, uint32_t tw, uint32_t begin,

@@ -24,6 +24,7 @@ struct Tuning {
     float ggx_core = 2.0f;         // multiple of alpha^2 below which the reference's own denominator is repeated
     int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
+    int lamb_hex = 1;              // ... over hexadecets (sign flips and the exchange of x and y) where the sizes allow (lambertian_hex.hip)
     int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
     int ggx_hex = 1;               // ... through the 16-fold symmetry where the sizes allow (ggx_hex.hip; 0: octets)
     int ggx_wg_waves = 0;          // waves (neighbouring units) per workgroup of ggx_hex_pairs: 0 = by input size, 1-4
@@ -72,6 +73,28 @@ hipError_t lambertian_split_launch(const LambertianOctPlan& pl, const float* d_e
                                    const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
                                    uint32_t out_begin, uint32_t out_count, float* d_out, void* d_rec, void* d_work,
                                    unsigned long long* d_counts, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+hipError_t lambertian_oct_exact_pass(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
+                                     const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
+                                     uint32_t out_begin, uint32_t out_count, float* d_out, void* d_rec, double* d_partial,
+                                     const uint32_t* d_flags, unsigned long long* counts,
+                                     hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+// lambertian_hex.hip: the split form over hexadecets (the 8 sign flips and the exchange of x and y), with
+// lambertian_octets.hip's kernels behind it for the octets it marks.  Output units of 64 hexadecets as in
+// ggx_hex.hip (the same unit lists and the same shard partition).
+struct LambertianHexPlan {
+    LambertianOctPlan oct;   // the second pass: the whole cube's octet blocks
+    uint32_t n_rec;          // input records: 64 per unit of the input cube
+    uint32_t slice_len, n_slices, n_runs;
+    uint32_t n_units;        // output units the call covers
+    size_t rec_bytes;        // the larger of the two passes' records
+    size_t work_bytes;       // header + the larger of the two passes' sums
+};
+bool lambertian_hex_eligible(uint32_t in_w, uint32_t out_size);
+LambertianHexPlan lambertian_hex_plan(uint32_t in_w, uint32_t out_size, uint32_t n_units, bool exact_in_runs = false);
+hipError_t lambertian_hex_launch(const LambertianHexPlan& hp, const float* d_env, uint32_t in_w, uint32_t out_size,
+                                 const uint32_t* d_units, uint32_t out_begin, uint32_t out_count, float* d_out,
+                                 void* d_rec, void* d_work, unsigned long long* d_counts, hipStream_t stream,
+                                 hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3);      // d_units null: every unit of the cube
 uint32_t lambertian_oct_blocks_total(uint32_t out_size);
 uint32_t lambertian_oct_tile_edge(uint32_t out_size);
 constexpr uint32_t LAMBERTIAN_OCT_BLOCK = 256;   // output octets per workgroup

@@ -461,6 +461,43 @@ LambertianOctPlan lambertian_oct_plan(uint32_t in_w, uint32_t out_blocks) {
     return pl;
 }
 
+// The kernels of this file over the octets of a call; d_flags (or null: every octet) as described at
+// lambertian_oct_prep, d_partial the sums workspace behind whatever header the pass in front keeps.
+hipError_t lambertian_oct_exact_pass(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
+                                     const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
+                                     uint32_t out_begin, uint32_t out_count, float* d_out, void* d_rec, double* d_partial,
+                                     const uint32_t* d_flags, unsigned long long* counts,
+                                     hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    const uint32_t oct_local_all = pl.out_blocks * OCT_THREADS;
+    lambertian_oct_prep<<<(pl.n_oct_in + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, in_w, pl.n_oct_in,
+                                                                       d_flags ? d_flags + oct_local_all + pl.out_blocks : nullptr,
+                                                                       (float4*)d_rec);
+    const uint32_t oct_local = pl.out_blocks * OCT_THREADS;
+    const uint32_t n_slots = pl.run ? pl.n_runs : pl.n_slices;
+    const uint32_t affine = (n_slots >= 8 && tuning().lamb_oct_affine != 0) ? 1u : 0u;
+    const dim3 grid(pl.out_blocks * (affine ? (n_slots + 7) / 8 * 8 : n_slots));
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    // workspace: the run sums first, then (slice form) the slice sums
+    double* d_runs = d_partial;
+    float* d_slices = (float*)(d_partial + (size_t)pl.n_runs * 24 * oct_local);
+    auto go = [&](auto kernel, void* d_store) {
+        kernel<<<grid, OCT_THREADS, 0, stream>>>(
+            (const float4*)d_rec, pl.n_oct_in, pl.slice_len, pl.n_slices, out_size, d_block_list, oct_begin, oct_end,
+            pl.out_blocks, affine, out_begin, out_count, d_flags, d_store, counts);
+    };
+    if (pl.run) { if (counts) go(lambertian_oct_pairs<true, true>, d_runs); else go(lambertian_oct_pairs<true, false>, d_runs); }
+    else        { if (counts) go(lambertian_oct_pairs<false, true>, d_slices); else go(lambertian_oct_pairs<false, false>, d_slices); }
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);
+    if (!pl.run)
+        lambertian_oct_reduce<<<dim3((oct_local + 255) / 256, 8, pl.n_runs), 256, 0, stream>>>(
+            (const float*)d_slices, pl.n_slices, oct_local, d_flags, d_runs);
+    lambertian_oct_final<<<dim3((oct_local + 255) / 256, 8), 256, 0, stream>>>(
+        d_runs, pl.n_runs, out_size, d_block_list, oct_begin, oct_end, oct_local, out_begin, out_count, scale, d_flags,
+        (float4*)d_out);
+    return hipGetLastError();
+}
+
 hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env, uint32_t in_w, uint32_t out_size,
                                  const uint32_t* d_block_list, uint32_t oct_begin, uint32_t oct_end,
                                  uint32_t out_begin, uint32_t out_count,
@@ -479,36 +516,9 @@ hipError_t lambertian_oct_launch(const LambertianOctPlan& pl, const float* d_env
         ev0 = ev2;      // this pass's pair kernel is timed by the call's second pair of events
         ev1 = ev3;
     }
-    const uint32_t oct_local_all = pl.out_blocks * OCT_THREADS;
-    lambertian_oct_prep<<<(pl.n_oct_in + 255) / 256, 256, 0, stream>>>((const float4*)d_env, in_w, in_w, pl.n_oct_in,
-                                                                       d_flags ? d_flags + oct_local_all + pl.out_blocks : nullptr,
-                                                                       (float4*)d_rec);
-    const uint32_t oct_local = pl.out_blocks * OCT_THREADS;
-    const uint32_t n_slots = pl.run ? pl.n_runs : pl.n_slices;
-    const uint32_t affine = (n_slots >= 8 && tuning().lamb_oct_affine != 0) ? 1u : 0u;
-    const dim3 grid(pl.out_blocks * (affine ? (n_slots + 7) / 8 * 8 : n_slots));
-    if (ev0) (void)hipEventRecord(ev0, stream);
-    // workspace: the run sums first, then (slice form) the slice sums
-    double* d_runs = d_partial;
-    float* d_slices = (float*)(d_partial + (size_t)pl.n_runs * 24 * oct_local);
     // (the second pass does not count: the counters price the kernel that does the work)
-    unsigned long long* counts = pl.split ? nullptr : d_counts;
-    auto go = [&](auto kernel, void* d_store) {
-        kernel<<<grid, OCT_THREADS, 0, stream>>>(
-            (const float4*)d_rec, pl.n_oct_in, pl.slice_len, pl.n_slices, out_size, d_block_list, oct_begin, oct_end,
-            pl.out_blocks, affine, out_begin, out_count, d_flags, d_store, counts);
-    };
-    if (pl.run) { if (counts) go(lambertian_oct_pairs<true, true>, d_runs); else go(lambertian_oct_pairs<true, false>, d_runs); }
-    else        { if (counts) go(lambertian_oct_pairs<false, true>, d_slices); else go(lambertian_oct_pairs<false, false>, d_slices); }
-    if (ev1) (void)hipEventRecord(ev1, stream);
-    const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);
-    if (!pl.run)
-        lambertian_oct_reduce<<<dim3((oct_local + 255) / 256, 8, pl.n_runs), 256, 0, stream>>>(
-            (const float*)d_slices, pl.n_slices, oct_local, d_flags, d_runs);
-    lambertian_oct_final<<<dim3((oct_local + 255) / 256, 8), 256, 0, stream>>>(
-        d_runs, pl.n_runs, out_size, d_block_list, oct_begin, oct_end, oct_local, out_begin, out_count, scale, d_flags,
-        (float4*)d_out);
-    return hipGetLastError();
+    return lambertian_oct_exact_pass(pl, d_env, in_w, out_size, d_block_list, oct_begin, oct_end, out_begin, out_count, d_out,
+                                     d_rec, d_partial, d_flags, pl.split ? nullptr : d_counts, stream, ev0, ev1);
 }
 
 }  // namespace ibl
