@@ -76,3 +76,36 @@ def test_hot_kernels_have_no_scratch(source, kernel):
             found += 1
             assert k.get("VGPRs Spill", 0) == 0 and k.get("ScratchSize [bytes/lane]", 0) == 0, k
     assert found >= 1
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("source,kernel", [("lambertian_split.hip", "ls_pairs"), ("lambertian_hex.hip", "lh_pairs")])
+def test_the_prefetch_register_belongs_to_the_prefetch_alone(source, kernel):
+    """These kernels touch records ahead with a vector load that nobody waits for; its result arrives in a
+    register whenever it arrives.  The compiler only knows that the register is written where the instruction
+    stands, so the build must leave that register to this one instruction: no other use, no copy, no spill."""
+    import re
+    lines = check_scalar_loads.assembly(os.path.join(CSRC, source))
+    checked = 0
+    for name, body in check_scalar_loads.functions(lines):
+        if kernel not in name:
+            continue
+        code = [l.split(";")[0].strip() for l in body]
+        code = [l for l in code if l and not l.startswith(".")]
+        unread = []
+        for l in code:
+            m = re.match(r"global_load_dword (v\d+),", l)
+            if not m:
+                continue
+            reg = int(m.group(1)[1:])
+
+            def touches(text):
+                if re.search(r"\bv%d\b" % reg, text):
+                    return True
+                return any(int(a) <= reg <= int(b) for a, b in re.findall(r"v\[(\d+):(\d+)\]", text))
+            others = [o for o in code if o is not l and touches(o)]
+            if not others:
+                unread.append(reg)
+        assert len(unread) == 1, (name, unread)          # the prefetch, and its register is nobody else's
+        checked += 1
+    assert checked >= 1

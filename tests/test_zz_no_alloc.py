@@ -45,6 +45,15 @@ def test_static_scratch_lambertian_equals_the_allocating_entry_point(ibl, orc):
         ibl.set_counting(False)
 
 
+@pytest.mark.parametrize("in_w,out_w", [(512, 32), (256, 64), (128, 64)])
+def test_static_scratch_holds_the_sizes_the_header_names(ibl, orc, in_w, out_w):
+    t = ibl.torch
+    env = _env(ibl, orc, in_w, 6)
+    got = t.full((6, out_w, out_w, 4), -1.0, dtype=t.float32, device=ibl.device)
+    ibl.lambertian_static(env, out_w, got)
+    assert t.equal(got, ibl.lambertian(env, out_w))
+
+
 def test_static_scratch_lambertian_rejects_what_does_not_fit(ibl, orc):
     t = ibl.torch
     env = t.ones((6, 1024, 1024, 4), dtype=t.float32, device=ibl.device)
