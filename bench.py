@@ -636,6 +636,20 @@ def main():
         finally:
             ibl.set_tuning("lamb_split", 1)
 
+    # ... and on the split form over octets (what the hexadecet form replaced where the sizes allow it).
+    if args.workload == "c4" and not args.no_extras and getattr(wl, "hex", False):
+        ibl.set_tuning("lamb_hex", 0)
+        try:
+            wo = Workload("c4", args, ibl, rank, world, dist)
+            o_elapsed, o_kernel_ms = run_timed(wo, 5, 1, torch, dist, world, ibl.device)
+            if line is not None:
+                line["c4_octets_split_ms_per_step"] = round(o_elapsed / 5 * 1e3, 4)
+                line["c4_octets_split_kernel"] = wo.kernel
+                line["c4_octets_split_kernel_ms"] = round(o_kernel_ms, 4)
+            del wo
+        finally:
+            ibl.set_tuning("lamb_hex", 1)
+
     # The rest of the bake: the GGX chains of configurations 3 and 5, every rank taking part.
     if args.workload == "c4" and not args.no_extras:
         del wl
