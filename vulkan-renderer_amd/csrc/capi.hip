@@ -662,7 +662,7 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
     const uint32_t n_out = out_size * out_size * 6;
     if (use_lamb_hex(in_w, out_size)) {
         // the passes ibl_lambertian_dev runs for these sizes, over every unit of the cube (no list)
-        const ibl::LambertianHexPlan hp = ibl::lambertian_hex_plan(in_w, out_size, ibl::ggx_hex_units_total(out_size), true);
+        const ibl::LambertianHexPlan hp = ibl::lambertian_hex_plan(in_w, out_size, ibl::ggx_hex_units_total(out_size));
         const size_t rec_bytes = (hp.rec_bytes + 255) & ~(size_t)255;
         if (rec_bytes + hp.work_bytes > STATIC_SCRATCH_BYTES)
             return fail(IBL_EINVAL, "lambertian_static: %u x %u/face -> %u x %u/face needs %zu bytes of scratch, the "

@@ -90,7 +90,7 @@ struct LambertianHexPlan {
     size_t work_bytes;       // header + the larger of the two passes' sums
 };
 bool lambertian_hex_eligible(uint32_t in_w, uint32_t out_size);
-LambertianHexPlan lambertian_hex_plan(uint32_t in_w, uint32_t out_size, uint32_t n_units, bool exact_in_runs = false);
+LambertianHexPlan lambertian_hex_plan(uint32_t in_w, uint32_t out_size, uint32_t n_units);
 hipError_t lambertian_hex_launch(const LambertianHexPlan& hp, const float* d_env, uint32_t in_w, uint32_t out_size,
                                  const uint32_t* d_units, uint32_t out_begin, uint32_t out_count, float* d_out,
                                  void* d_rec, void* d_work, unsigned long long* d_counts, hipStream_t stream,

@@ -59,7 +59,9 @@ __device__ __forceinline__ double lh_sign(uint32_t k, uint32_t s) { return (__po
 // (0 for a hexadecet on the diagonal, which is its own partner).
 __global__ __launch_bounds__(256) void lh_prep(const float4* __restrict__ env, uint32_t w, uint32_t n_rec,
                                                 float4* __restrict__ rec, double* __restrict__ moment_parts) {
-    __shared__ double s_m[9][256];
+    // (one buffer for both uses: the records on their way out, then the moment's tree)
+    __shared__ float4 s_rec[256 * (LH_REC + 1)];
+    double (*s_m)[256] = (double (*)[256])s_rec;
     const uint32_t tid = threadIdx.x;
     const uint32_t k = blockIdx.x * blockDim.x + tid;
     double m[9];
@@ -110,9 +112,22 @@ __global__ __launch_bounds__(256) void lh_prep(const float4* __restrict__ env, u
                     m[ax * 3 + ch] = (double)g[ax] * v0 + (double)gp[ax] * v1;
                 }
         }
-        float4* dst = rec + (size_t)k * LH_REC;
+    }
+    // The workgroup's 256 records leave through LDS, so that neighbouring threads store neighbouring 16-byte
+    // words (a thread storing its own 128 bytes writes eight quarter-filled lines per instruction; rows of
+    // 9 words keep the LDS writes off each other's banks).
+    {
 #pragma unroll
-        for (int q = 0; q < LH_REC; q++) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+        for (int q = 0; q < LH_REC; q++)
+            s_rec[tid * (LH_REC + 1) + q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+        __syncthreads();
+        const size_t base = (size_t)blockIdx.x * 256 * LH_REC, end = (size_t)n_rec * LH_REC;
+#pragma unroll
+        for (int q = 0; q < LH_REC; q++) {
+            const uint32_t f = (uint32_t)q * 256u + tid;
+            if (base + f < end) rec[base + f] = s_rec[(f / LH_REC) * (LH_REC + 1) + f % LH_REC];
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int q = 0; q < 9; q++) s_m[q][tid] = m[q];
@@ -372,6 +387,7 @@ __global__ __launch_bounds__(64 * LH_FINAL_PARTS) void lh_final(
     const F3 n = ref_normalize(ref_normal_from(c.face, c.x, c.y, out_size, out_size));
     const uint32_t hw = out_size / 2;          // tw: the tile edge of the octet numbering
     uint32_t n_bad = 0;
+#pragma unroll 1
     for (uint32_t half = 0; half < (hl.diagonal ? 1u : 2u); half++) {
         const double nn[3] = { half ? (double)n.y : (double)n.x, half ? (double)n.x : (double)n.y, (double)n.z };
         bool bad = false;
@@ -417,11 +433,13 @@ bool lambertian_hex_eligible(uint32_t in_w, uint32_t out_size) {
 
 // Slices of the input hexadecets: as many as the octet plan has for this input size (the count fixes
 // the order of the sums, so it depends on the input size only).
-LambertianHexPlan lambertian_hex_plan(uint32_t in_w, uint32_t out_size, uint32_t n_units, bool exact_in_runs) {
+LambertianHexPlan lambertian_hex_plan(uint32_t in_w, uint32_t out_size, uint32_t n_units) {
     LambertianHexPlan hp;
     hp.oct = lambertian_oct_plan(in_w, lambertian_oct_blocks_total(out_size));
-    // (the second pass in its run form keeps an eighth of the sums and gives the same bits)
-    if (exact_in_runs) hp.oct.run = hp.oct.n_slices > 1;
+    // The second pass in its run form: it is offered every octet block of the cube whatever the call covers, so
+    // an eighth of the sums (and one launch less when nothing is marked, the usual case) is worth more than the
+    // slice form's 15 % on the marked blocks; the two forms give the same bits.
+    hp.oct.run = hp.oct.n_slices > 1;
     hp.n_rec = hex_units_total(in_w) * GH_UNIT;
     hp.slice_len = (hp.n_rec + hp.oct.n_slices - 1) / hp.oct.n_slices;
     if (hp.slice_len < 2) hp.slice_len = 2;
