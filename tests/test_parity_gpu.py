@@ -894,7 +894,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu(ibl, orc):
     os.environ.get("IBL_TEST_HUGE") != "1", reason="6.4 GB environment; set IBL_TEST_HUGE=1"))])
 def test_largest_inputs(ibl, orc, w):
     """A 4096x4096/face environment (1e8 texels, 1.6 GB decoded) and, on request, 8192x8192
-    (6.4 GB: byte offsets beyond 32 bits): Lambertian 16x16/face and the two extreme GGX levels
+    (6.4 GB: byte offsets beyond 32 bits): Lambertian 16x16 and 32x32/face and the two extreme GGX levels
     of the chain, a few output texels each against the oracle."""
     rep = w // 512
     small = vra.synth.hdr_environment(512, seed=9).reshape(6, 512, 512, 4)
@@ -908,6 +908,9 @@ def test_largest_inputs(ibl, orc, w):
     got = ibl.lambertian(env_d, 16).cpu().numpy()
     want = orc.lambertian(env, 16, out_begin=begin, out_count=8)
     _check_cube(orc, got, want, sel=slice(begin, begin + 8), label="lambertian %d" % w)
+    got = ibl.lambertian(env_d, 32).cpu().numpy()                         # (32: the hexadecet form)
+    want = orc.lambertian(env, 32, out_begin=begin, out_count=8)
+    _check_cube(orc, got, want, sel=slice(begin, begin + 8), label="lambertian %d -> 32" % w)
     mips = ibl.ggx_mip_levels(w, w, 16)
     assert mips == orc.ggx_mip_levels(w, w, 16) == {4096: 8, 8192: 9}[w]
     got = ibl.ggx_level(env_d, 16, mips, mips).cpu().numpy()             # roughness 1: every texel of the hemisphere
