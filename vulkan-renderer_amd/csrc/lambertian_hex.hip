@@ -441,7 +441,11 @@ LambertianHexPlan lambertian_hex_plan(uint32_t in_w, uint32_t out_size, uint32_t
     // slice form's 15 % on the marked blocks; the two forms give the same bits.
     hp.oct.run = hp.oct.n_slices > 1;
     hp.n_rec = hex_units_total(in_w) * GH_UNIT;
-    hp.slice_len = (hp.n_rec + hp.oct.n_slices - 1) / hp.oct.n_slices;
+    // At most 341 slices, 512 from 1024 x 1024 faces on (or what the knob says): on the 1024 -> 128 cube 512 beat
+    // 430 by 2-6 % on 1, 2, 4 and 8 shards alike (a wave is a fifth shorter, and an eighth of that cube is a single
+    // round of waves and a tail); 683 to 1024 gain nothing more and write more sums (tools/lamb_slices_sweep.py).
+    const uint32_t max_slices = tuning().lamb_oct_slices ? hp.oct.n_slices : (hp.n_rec >= 262144u ? 512u : hp.oct.n_slices);
+    hp.slice_len = (hp.n_rec + max_slices - 1) / max_slices;
     if (hp.slice_len < 2) hp.slice_len = 2;
     hp.n_slices = (hp.n_rec + hp.slice_len - 1) / hp.slice_len;
     hp.n_runs = (hp.n_slices + LH_RUN - 1) / LH_RUN;
