@@ -761,7 +761,9 @@ GgxOctPlan ggx_hex_plan(uint32_t in_w, uint32_t out_w, uint32_t mip, uint32_t mi
     pl.n_po = hex_patches_total(pw);
     pl.tw = GH_TILE;
     const uint32_t units_level = hex_units_total(out_w);
-    ggx_plan_runs(pl, units_level * GH_UNIT, units_level, 16, GH_SUMS, (size_t)GH_REC_BYTES, n_units);
+    // (at most 200 000 waves: a wave of this kernel sets up more than an octet wave does, and with the 4064 runs the
+    // shared rule gives the 2048 -> 128 level a run is one or two patches: 51.2 ms, 48.7 with 1000 or 2000 runs)
+    ggx_plan_runs(pl, units_level * GH_UNIT, units_level, 16, GH_SUMS, (size_t)GH_REC_BYTES, n_units, 200000.0);
     pl.marks = tuning().ggx_few > 0.0f;
     pl.mx_bytes = (size_t)pl.n_po * ps * ps * (size_t)GH_REC_BYTES;
     pl.rec_bytes = pl.mx_bytes;

@@ -809,7 +809,7 @@ uint32_t ggx_oct_tile_edge(uint32_t out_w) { return go_tile_edge(out_w / 2); }
 // pl.matrix are set by the caller; lanes_level and units_level describe the whole level (runs and
 // subsets come from the level geometry only: range/shard independence), n_units the call.
 void ggx_plan_runs(GgxOctPlan& pl, uint32_t lanes_level, uint32_t units_level, uint32_t members, uint32_t sums,
-                   size_t rec_each, uint32_t n_units) {
+                   size_t rec_each, uint32_t n_units, double max_waves) {
     pl.accumulate = false;
     const uint32_t ps = pl.lv.patch;
     // Enough waves that an eighth of the level (one of 8 GPUs) still fills a GPU (6144 wave
@@ -821,7 +821,7 @@ void ggx_plan_runs(GgxOctPlan& pl, uint32_t lanes_level, uint32_t units_level, u
     const double wave_records = (double)lanes_level / 64.0 * (double)pl.n_po * ps * ps * (double)members * cone;
     const double seconds = wave_records * 70e-9 / 1024.0;                // ~70 ns per wave, record and pattern per SIMD
     double waves = 0.04 * seconds * 1.5e12 / (64.0 * sums * 4.0);
-    waves = fmin(fmax(waves, 65536.0), 1048576.0);
+    waves = fmin(fmax(waves, 65536.0), max_waves);
     if (tuning().ggx_waves > 0.0) waves = tuning().ggx_waves;            // tuning knob
     uint32_t want = (uint32_t)ceil(waves / (double)units_level);
     // The waves in flight on an XCD work on one run (see ggx_oct_pairs) and on neighbouring

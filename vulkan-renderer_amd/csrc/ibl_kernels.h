@@ -168,7 +168,7 @@ struct GgxOctPlan {
     size_t pn_bytes;          // float4 per patch octet + one for the count of marked ones
 };
 void ggx_plan_runs(GgxOctPlan& pl, uint32_t lanes_level, uint32_t units_level, uint32_t members, uint32_t sums,
-                   size_t rec_each, uint32_t n_units);
+                   size_t rec_each, uint32_t n_units, double max_waves = 1048576.0);
 bool ggx_octets_eligible(uint32_t in_w, uint32_t out_w, uint32_t patch);
 uint32_t ggx_oct_tile_edge(uint32_t out_w);
 // The call covers the n_units 64-octet units d_units[0], d_units[1], ... (tile-major octet order).
