@@ -101,8 +101,9 @@ bool deflate_parallel(const unsigned char* raw, size_t raw_size, std::vector<uns
 
 // Undoes the per-row filters of one (sub-)image: rows of 1 + stride bytes in, stride bytes out.
 // bpp: bytes per complete pixel, at least 1 (the filter's "left" distance).
-bool unfilter_rows(const unsigned char* raw, size_t stride, uint32_t h, size_t bpp, unsigned char* img, std::string& err) {
-    for (uint32_t y = 0; y < h; y++) {
+bool unfilter_rows_range(const unsigned char* raw, size_t stride, uint32_t y0, uint32_t y1, size_t bpp, unsigned char* img,
+                         std::string& err) {
+    for (uint32_t y = y0; y < y1; y++) {
         const unsigned char* src = raw + (stride + 1) * y + 1;
         unsigned char* cur = img + stride * y;
         const unsigned char* up = y ? img + stride * (y - 1) : nullptr;
@@ -138,6 +139,10 @@ bool unfilter_rows(const unsigned char* raw, size_t stride, uint32_t h, size_t b
         }
     }
     return true;
+}
+
+bool unfilter_rows(const unsigned char* raw, size_t stride, uint32_t h, size_t bpp, unsigned char* img, std::string& err) {
+    return unfilter_rows_range(raw, stride, 0, h, bpp, img, err);
 }
 
 // Everything the fast path below leaves out: 1/2/4/16-bit samples, Adam7 interlacing, colour keys.
@@ -298,16 +303,64 @@ bool png_read_rgba8(const std::string& path, uint32_t& width, uint32_t& height, 
     }
     const size_t stride = (size_t)w * channels;
     std::vector<unsigned char> raw((stride + 1) * h);
-    uLongf raw_len = (uLongf)raw.size();
-    int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
-    if (zrc != Z_OK || raw_len != raw.size()) { err = "PNG image data is corrupt"; return false; }
-
     // RGBA8 input (what the tool's own strips are) is unfiltered straight into the result.
     std::vector<unsigned char> other;
     if (color == 6) rgba.resize(stride * h);
     else other.resize(stride * h);
     unsigned char* const img = color == 6 ? rgba.data() : other.data();
-    if (!unfilter_rows(raw.data(), stride, h, (size_t)channels, img, err)) return false;
+    // Inflate is serial by the format and the longest single step of a bake's start (a 2048 x 2048 strip: 100 MB,
+    // 0.3 s).  It hands over what it has every few megabytes, and a second thread undoes the row filters behind it.
+    {
+        std::atomic<size_t> ready{0};          // bytes of `raw` that are final
+        std::atomic<bool> failed{false};
+        std::string filter_err;
+        bool filter_ok = true;
+        std::thread rows([&]() {
+            uint32_t y = 0;
+            while (y < h) {
+                const size_t have = ready.load(std::memory_order_acquire);
+                const uint32_t upto = (uint32_t)std::min<size_t>(h, have / (stride + 1));
+                if (upto > y) {
+                    if (!unfilter_rows_range(raw.data(), stride, y, upto, (size_t)channels, img, filter_err)) { filter_ok = false; return; }
+                    y = upto;
+                } else if (failed.load(std::memory_order_acquire)) {
+                    return;
+                } else {
+                    std::this_thread::yield();
+                }
+            }
+        });
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        bool ok = inflateInit(&zs) == Z_OK;
+        if (ok) {
+            size_t in_at = 0, out_at = 0;
+            int zrc = Z_OK;
+            while (zrc == Z_OK) {
+                // (zlib counts in 32 bits: both sides are fed in pieces)
+                if (zs.avail_in == 0) {
+                    const size_t n = std::min<size_t>(idat.size() - in_at, (size_t)1 << 30);
+                    zs.next_in = idat.data() + in_at;
+                    zs.avail_in = (uInt)n;
+                    in_at += n;
+                }
+                const size_t room = std::min<size_t>(raw.size() - out_at, (size_t)4 << 20);
+                zs.next_out = raw.data() + out_at;
+                zs.avail_out = (uInt)room;
+                zrc = inflate(&zs, Z_NO_FLUSH);
+                out_at += room - zs.avail_out;
+                ready.store(out_at, std::memory_order_release);
+                if (zrc == Z_OK && room == 0) break;                    // more data than the header announced
+                if (zrc == Z_BUF_ERROR && zs.avail_in == 0 && in_at < idat.size()) zrc = Z_OK;
+            }
+            ok = zrc == Z_STREAM_END && out_at == raw.size();
+            inflateEnd(&zs);
+        }
+        if (!ok) failed.store(true, std::memory_order_release);
+        rows.join();
+        if (!ok) { err = "PNG image data is corrupt"; return false; }
+        if (!filter_ok) { err = filter_err; return false; }
+    }
 
     if (color != 6) rgba.resize((size_t)w * h * 4);
     for (size_t i = 0; color != 6 && i < (size_t)w * h; i++) {
