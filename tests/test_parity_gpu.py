@@ -228,18 +228,20 @@ def test_lambertian_config1_host_api(ibl, orc):
     _check_cube(orc, got, orc.lambertian(env, 32))
 
 
+@pytest.mark.parametrize("w,out", [(32, 16), (64, 32)])          # (the second pair: sizes the hexadecet form serves)
 @pytest.mark.parametrize("kind", ["const", "single"])
-def test_lambertian_special_environments(ibl, orc, kind, lamb_mode):
-    env, env_d = _env(ibl, orc, 32, kind=kind)
-    got = ibl.lambertian(env_d, 16).cpu().numpy()
-    want = orc.lambertian(env, 16)
+def test_lambertian_special_environments(ibl, orc, kind, lamb_mode, w, out):
+    env, env_d = _env(ibl, orc, w, kind=kind)
+    got = ibl.lambertian(env_d, out).cpu().numpy()
+    want = orc.lambertian(env, out)
     if kind == "single":
         # half the outputs see nothing: both must be exactly zero there
         zero = (want[..., :3] == 0).all(axis=-1)
         assert zero.any() and (got[..., :3][zero] == 0).all()
     # one term only: at grazing incidence its dot product cancels, so the per-texel
-    # error is a few float ulps of the operands, not of the result
-    _check_cube(orc, got, want, tight=2e-5 if kind == "single" else 5e-6)
+    # error is a few float ulps of the operands, not of the result -- and the finer the grids, the
+    # closer to grazing the closest pair (4.2e-5 at 64 -> 32 in every implementation, general kernel included)
+    _check_cube(orc, got, want, tight=(2e-5 if w == 32 else 1e-4) if kind == "single" else 5e-6)
 
 
 def test_lambertian_split_falls_back_where_it_cancels(ibl, orc):
