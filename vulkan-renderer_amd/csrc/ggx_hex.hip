@@ -41,8 +41,8 @@ namespace ibl {
 
 // Records per item of the launch that walks the marked patches: a whole patch.  (The octet kernel's vector
 // walk waits out a scalar load per record when it is alone on its SIMD and is dealt 64 records at a time;
-// this kernel's walk is pipelined, and what a wave pays per item is its set-up, so fewer, longer items:
-// with 64 records the launch took 208 us per level of the 512 chain.)
+// what a wave of this kernel pays per item is mostly its set-up and the fold of 64 accumulators, so fewer,
+// longer items: stretches of 64 records measured 1 % slower on the 512 chain.)
 constexpr uint32_t GH_MARK_PART = 256;
 constexpr int GH_SUMS = 50;                 // 16 members x RGB, then the weight sums of the two cosets
 constexpr uint32_t GH_GROUP_WORDS = 6 * 64; // 16-byte words per group of 16 records: (upper, middle, lower piece) x 2 tiles x 64 lanes
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void ggx_hex_prep(const float4* __restrict__ e
 // EXACT: three bf16 pieces per factor and six partial products (marked patches).
 // NARROW: the weight form for windows that end above the horizon (go_weight_quad).
 // MARKS: 0 every patch hexadecet; 1 all but the marked ones; 2 only the marked ones, dealt to the runs as
-// (patch, pattern, stretch of 64 records) items, and the run's sums are ADDED to what the launch before
+// (patch, pattern, stretch of GH_MARK_PART records) items, numbered pattern-major, and the run's sums are ADDED to what the launch before
 // (MARKS = 1, same grid) stored.
 template <bool EXACT, bool NARROW, int MARKS>
 __global__ __launch_bounds__(GO_WG * GH_WG_WAVES, EXACT ? 2 : GH_MIN_WAVES) void ggx_hex_pairs(
