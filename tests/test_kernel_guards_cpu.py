@@ -80,10 +80,12 @@ def test_hot_kernels_have_no_scratch(source, kernel):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("source,kernel", [("lambertian_split.hip", "ls_pairs"), ("lambertian_hex.hip", "lh_pairs")])
-def test_the_prefetch_register_belongs_to_the_prefetch_alone(source, kernel):
-    """These kernels touch records ahead with a vector load that nobody waits for; its result arrives in a
-    register whenever it arrives.  The compiler only knows that the register is written where the instruction
-    stands, so the build must leave that register to this one instruction: no other use, no copy, no spill."""
+def test_loads_nobody_waits_for_have_no_destination_register(source, kernel):
+    """These kernels touch records ahead with a load that nobody waits for.  Such a load must not name a
+    register: its data arrives whenever it arrives, and a compiler that only knows where the instruction
+    stands is free to hand the register to another value in between (a build that did faulted the GPU).
+    So the touch is a load into LDS; every load into a register has a reader; and the wave waits for
+    everything on its way into LDS before it ends."""
     import re
     lines = check_scalar_loads.assembly(os.path.join(CSRC, source))
     checked = 0
@@ -92,20 +94,24 @@ def test_the_prefetch_register_belongs_to_the_prefetch_alone(source, kernel):
             continue
         code = [l.split(";")[0].strip() for l in body]
         code = [l for l in code if l and not l.startswith(".")]
-        unread = []
-        for l in code:
-            m = re.match(r"global_load_dword (v\d+),", l)
+        to_lds = [i for i, l in enumerate(code) if l.startswith("global_load_lds_dword")]
+        assert to_lds, name
+        assert any(l.startswith("s_waitcnt") and "vmcnt(0)" in l for l in code[to_lds[-1]:]), name
+        for i, l in enumerate(code):
+            m = re.match(r"global_load_dword(?:x\d)? (v\d+|v\[\d+:\d+\]),", l)
             if not m:
                 continue
-            reg = int(m.group(1)[1:])
+            regs = re.findall(r"\d+", m.group(1))
+            lo, hi = int(regs[0]), int(regs[-1])
 
-            def touches(text):
-                if re.search(r"\bv%d\b" % reg, text):
-                    return True
-                return any(int(a) <= reg <= int(b) for a, b in re.findall(r"v\[(\d+):(\d+)\]", text))
-            others = [o for o in code if o is not l and touches(o)]
-            if not others:
-                unread.append(reg)
-        assert len(unread) == 1, (name, unread)          # the prefetch, and its register is nobody else's
+            def reads(text):
+                ops = text.split(None, 1)[1] if " " in text else ""
+                srcs = ops.split(",", 1)[1] if "," in ops else ""          # everything behind the first operand
+                if text.startswith(("global_store", "scratch_store", "ds_write", "buffer_store")):
+                    srcs = ops
+                singles = [int(v) for v in re.findall(r"\bv(\d+)\b", srcs)]
+                ranges = [(int(a), int(b)) for a, b in re.findall(r"v\[(\d+):(\d+)\]", srcs)]
+                return any(lo <= v <= hi for v in singles) or any(a <= hi and lo <= b for a, b in ranges)
+            assert any(reads(o) for o in code[i + 1:] + code[:i]), (name, l)
         checked += 1
     assert checked >= 1

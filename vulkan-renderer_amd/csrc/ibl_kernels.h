@@ -84,7 +84,7 @@ hipError_t lambertian_oct_exact_pass(const LambertianOctPlan& pl, const float* d
 struct LambertianHexPlan {
     LambertianOctPlan oct;   // the second pass: the whole cube's octet blocks
     uint32_t n_rec;          // input records: 64 per unit of the input cube
-    uint32_t slice_len, n_slices, n_runs;
+    uint32_t slice_len, n_slices, n_runs;      // n_runs: groups of slices whose sums a workgroup adds
     uint32_t n_units;        // output units the call covers
     size_t rec_bytes;        // the larger of the two passes' records
     size_t work_bytes;       // header + the larger of the two passes' sums

@@ -32,24 +32,26 @@
 //               ggx_hex.hip; lanes above the diagonal of a diagonal tile get a zero record): the
 //               128-byte record, and the hexadecet's share of the first moment.
 //   lh_moment   the workgroups' shares in a fixed order.
-//   lh_pairs    grid = (groups of 4 output units) x (input slices); every wave works alone on 64 output
-//               hexadecets and walks the slice's records with scalar loads, two register sets.
-//               FP32 sums over 128 records, FP64 over the slice, stored as FP32 slice sums.
-//   lh_reduce / lh_final   runs of 8 slices, then all runs, in FP64; inverse transforms, the odd half,
-//               the scale, the cancellation measured per texel; marks are set per OCTET in the numbering
-//               of lambertian_octets.hip, whose kernels redo the marked octets.
+//   lh_pairs    grid = (output units) x (groups of 4 input slices); a workgroup is one unit of 64 output
+//               hexadecets and one group, a wave per slice; every wave walks its slice's records with scalar
+//               loads, two register sets.  FP32 sums over 128 records, FP64 over the slice; the slices' sums,
+//               rounded to FP32, meet in LDS and leave as the group's FP64 sum (no pass over slice sums: as
+//               a separate kernel that read 315 MB and took 75 us of a 2.78 ms call).
+//   lh_final    all groups in FP64; inverse transforms, the odd half, the scale, the cancellation measured
+//               per texel; marks are set per OCTET in the numbering of lambertian_octets.hip, whose kernels
+//               redo the marked octets.
 #include "ibl_device.h"
 #include "ibl_kernels.h"
 
 namespace ibl {
 
-constexpr int LH_THREADS = 256;       // 4 waves, each its own unit of 64 output hexadecets
+constexpr int LH_RUN = 4;             // slices per workgroup: their sums are added in the workgroup
+constexpr int LH_THREADS = 64 * LH_RUN;
 constexpr int LH_REC = 8;             // float4 per input hexadecet record
 constexpr int LH_SUMS = 24;
 #ifndef LH_CHUNK
 #define LH_CHUNK 128                  // records per FP32 sum (a power of two)
 #endif
-constexpr int LH_RUN = 8;             // slices per run
 constexpr uint32_t LH_OCT_BLOCK = 256;      // the octet blocks of lambertian_octets.hip (marks)
 
 __device__ __forceinline__ double lh_sign(uint32_t k, uint32_t s) { return (__popc(k & s) & 1) ? -1.0 : 1.0; }
@@ -179,7 +181,7 @@ __device__ __forceinline__ void lh_rec_wait(LhRec& r) {
 #define LH_MIN_WAVES 1
 #endif
 #ifndef LH_PREFETCH
-#define LH_PREFETCH 8          // records a wave touches ahead of its scalar loads (see lambertian_split.hip)
+#define LH_PREFETCH 1          // the waves touch records ahead of their scalar loads (see lambertian_split.hip); 0: they do not
 #endif
 
 // Does the unit hold a texel of the (face, y, x) range?  (Whole cubes and shards skip the test.)
@@ -200,24 +202,27 @@ template <bool COUNT>
 __global__ __launch_bounds__(LH_THREADS, LH_MIN_WAVES) void lh_pairs(
     const float4* __restrict__ rec, uint32_t n_rec_in, uint32_t slice_len, uint32_t n_slices,
     uint32_t out_size, const uint32_t* __restrict__ units, uint32_t n_units, uint32_t out_groups, uint32_t xcd_affine,
-    uint32_t out_begin, uint32_t out_count, float* __restrict__ partial, unsigned long long* __restrict__ counts) {
+    uint32_t out_begin, uint32_t out_count, double* __restrict__ partial, unsigned long long* __restrict__ counts) {
+    // The workgroup: one output unit, LH_RUN consecutive slices, a wave each; their sums meet in LDS at the end.
+    __shared__ float s_slice[LH_RUN - 1][LH_SUMS][64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    uint32_t slice, og;
-    if (xcd_affine) {                                   // XCD k works on slices k, k + 8, ...
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: the record addresses hang on it)
+    const uint32_t n_sgroups = (n_slices + LH_RUN - 1) / LH_RUN;
+    uint32_t sg, u;
+    if (xcd_affine) {                                   // XCD k works on the slice groups k, k + 8, ...
         const uint32_t seq = blockIdx.x >> 3;
-        slice = (blockIdx.x & 7u) + 8u * (seq / out_groups);
-        og = seq % out_groups;
-        if (slice >= n_slices) return;
+        sg = (blockIdx.x & 7u) + 8u * (seq / out_groups);
+        u = seq % out_groups;
+        if (sg >= n_sgroups) return;
     } else {
-        slice = blockIdx.x / out_groups;
-        og = blockIdx.x % out_groups;
+        sg = blockIdx.x / out_groups;
+        u = blockIdx.x % out_groups;
     }
-    const uint32_t u = og * (LH_THREADS / 64) + (tid >> 6);          // the wave's unit of the call
-    if (u >= n_units) return;                                         // no barrier anywhere below: a wave may leave alone
+    const uint32_t slice = sg * LH_RUN + wave;
     const uint32_t lo = u * GH_UNIT + lane;
     const uint32_t hex_local = n_units * GH_UNIT;
     const HexLane hl = hex_unit_lane(units ? units[u] : u, lane, out_size / 2);
-    if (!__any(lh_lane_wanted(hl, out_size, out_begin, out_count))) return;
+    if (!__any(lh_lane_wanted(hl, out_size, out_begin, out_count))) return;     // (the same in all waves of the workgroup)
 
     Texel c = octet_member(hl.axis, hl.j, hl.i, 0, out_size, out_size);
     const F3 n = ref_normalize(ref_normal_from(c.face, c.x, c.y, out_size, out_size));   // cube.cpp:97
@@ -233,10 +238,10 @@ __global__ __launch_bounds__(LH_THREADS, LH_MIN_WAVES) void lh_pairs(
 #pragma unroll
     for (int q = 0; q < LH_SUMS; q++) dacc[q] = 0.0;
 
-    const uint32_t in0 = slice * slice_len;
+    const uint32_t in0 = min(n_rec_in, slice * slice_len);
     const uint32_t in1 = min(n_rec_in, in0 + slice_len);
-    const uint32_t n_rec = in1 - in0;                                // >= 1
-    const float4* __restrict__ rp = rec + (size_t)in0 * LH_REC;      // wave-uniform
+    const uint32_t n_rec = in1 - in0;                                // (0 for the waves past the last slice)
+    const float4* __restrict__ rp = rec + (size_t)min(in0, n_rec_in - 1u) * LH_REC;      // wave-uniform
 
     const f32x2 nx = { n.x, n.x }, ny = { n.y, n.y };
     auto eval = [&](const LhRec& r) __attribute__((always_inline)) {
@@ -288,19 +293,21 @@ __global__ __launch_bounds__(LH_THREADS, LH_MIN_WAVES) void lh_pairs(
     };
 
     LhRec ra, rb;
-    const uint32_t last = n_rec - 1u;
+    const uint32_t last = n_rec ? n_rec - 1u : 0u;
 #if LH_PREFETCH
-    // The two records LH_PREFETCH ahead are touched, one per half of the wave, with a vector load nobody waits for.
-    const uint32_t pf_off = (n_rec > 1u && lane >= 32u) ? (uint32_t)(LH_REC * sizeof(float4)) : 0u;
-    const uint32_t pf_last = last > 0u ? last - 1u : 0u;
-    float pf_sink;
+    // Every 64 records the wave touches the 64 records after those, a lane each, with a load nobody waits for:
+    // a load into LDS, which has no destination register that could be handed to another value while the data is
+    // on its way (the words land in s_touch and are never looked at).
+    __shared__ float s_touch[64];
+    typedef __attribute__((address_space(1))) const void* lh_gptr;
+    typedef __attribute__((address_space(3))) void* lh_lptr;
 #endif
     lh_rec_load(ra, rp);
     for (uint32_t e = 0; e < n_rec; e += 2) {
 #if LH_PREFETCH
-        {
-            const float4* pp = rp + (size_t)min(e + (uint32_t)LH_PREFETCH, pf_last) * LH_REC;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(pf_sink) : "v"(pf_off), "s"(pp));
+        if ((e & 63u) == 0u) {
+            const float4* pp = rp + (size_t)min(e + 64u + lane, last) * LH_REC;
+            __builtin_amdgcn_global_load_lds((lh_gptr)pp, (lh_lptr)s_touch, 4, 0, 0);
         }
 #endif
         lh_rec_wait(ra);
@@ -313,40 +320,31 @@ __global__ __launch_bounds__(LH_THREADS, LH_MIN_WAVES) void lh_pairs(
     }
     lh_rec_wait(ra);       // nothing is in flight when the wave ends
 #if LH_PREFETCH
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink));
+    // (nothing may still be on its way into the workgroup's LDS when the wave ends)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    { const float seen = s_touch[lane]; asm volatile("" : : "v"(seen)); }
 #endif
     flush();
 
-    if (hl.valid) {
+    // The slices' sums as FP32, added in slice order in FP64 by the first wave: the group's sum.
+    if (wave > 0) {
 #pragma unroll
-        for (int q = 0; q < LH_SUMS; q++)
-            partial[((size_t)slice * LH_SUMS + q) * hex_local + lo] = (float)dacc[q];
+        for (int q = 0; q < LH_SUMS; q++) s_slice[wave - 1][q][lane] = (float)dacc[q];
+    }
+    __syncthreads();
+    if (wave == 0 && hl.valid) {
+#pragma unroll
+        for (int q = 0; q < LH_SUMS; q++) {
+            double v = (double)(float)dacc[q];
+#pragma unroll
+            for (int k = 0; k < LH_RUN - 1; k++) v += (double)s_slice[k][q][lane];
+            partial[((size_t)sg * LH_SUMS + q) * hex_local + lo] = v;
+        }
     }
     if (COUNT && lane == 0u) {
         atomicAdd(&counts[3], (unsigned long long)n_rec);
         atomicAdd(&counts[4], (unsigned long long)n_rec * 8ull);      // eight coefficients per record
     }
-}
-
-// The run sums from the slice sums: one thread per (four output hexadecets, sum, run), the slices of a
-// run in order (a slice missing at the end of the last run counts as +0).
-__global__ __launch_bounds__(256) void lh_reduce(const float* __restrict__ partial, uint32_t n_slices,
-                                                  uint32_t hex_local, double* __restrict__ reduced) {
-    const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;      // hex_local is a multiple of 64
-    const uint32_t q = blockIdx.y, g = blockIdx.z;
-    if (lo >= hex_local) return;
-    const uint32_t s0 = g * LH_RUN;
-    float4 v[LH_RUN];
-#pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)LH_RUN; k++)
-        v[k] = s0 + k < n_slices ? *(const float4*)(partial + ((size_t)(s0 + k) * LH_SUMS + q) * hex_local + lo)
-                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-#pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)LH_RUN; k++) { a += (double)v[k].x; b += (double)v[k].y; c += (double)v[k].z; d += (double)v[k].w; }
-    double* out = reduced + ((size_t)g * LH_SUMS + q) * hex_local + lo;
-    *(double2*)out = make_double2(a, b);
-    *(double2*)(out + 2) = make_double2(c, d);
 }
 
 // The runs of an output hexadecet added up (8 interleaved parts, then those, as ls_final), the inverse
@@ -453,7 +451,7 @@ LambertianHexPlan lambertian_hex_plan(uint32_t in_w, uint32_t out_size, uint32_t
     const size_t hex_rec = (size_t)hp.n_rec * LH_REC * sizeof(float4);
     hp.rec_bytes = hex_rec > hp.oct.rec_bytes ? hex_rec : hp.oct.rec_bytes;
     const size_t sums = (size_t)LH_SUMS * n_units * GH_UNIT;
-    const size_t fast = sums * sizeof(double) * hp.n_runs + sums * sizeof(float) * hp.n_slices;
+    const size_t fast = sums * sizeof(double) * hp.n_runs;
     const size_t exact = (size_t)24 * hp.oct.out_blocks * LH_OCT_BLOCK
                          * (sizeof(double) * hp.oct.n_runs + (hp.oct.run ? 0 : sizeof(float) * hp.oct.n_slices));
     hp.work_bytes = lambertian_split_header_bytes(hp.oct.n_oct_in, hp.oct.out_blocks) + (fast > exact ? fast : exact);
@@ -474,25 +472,22 @@ hipError_t lambertian_hex_launch(const LambertianHexPlan& hp, const float* d_env
     double* d_moment = (double*)((char*)d_work + flags_bytes);
     double* d_parts = (double*)((char*)d_work + flags_bytes + 256);
     char* d_sums = (char*)d_work + lambertian_split_header_bytes(op.n_oct_in, op.out_blocks);
-    const uint32_t hex_local = hp.n_units * GH_UNIT;
     double* d_runs = (double*)d_sums;
-    float* d_slices = (float*)(d_runs + (size_t)hp.n_runs * LH_SUMS * hex_local);
 
     if (hipError_t e = hipMemsetAsync(d_flags, 0, flags_bytes, stream); e != hipSuccess) return e;
     lh_prep<<<prep_blocks, 256, 0, stream>>>((const float4*)d_env, in_w, hp.n_rec, (float4*)d_rec, d_parts);
     lh_moment<<<1, 256, 0, stream>>>(d_parts, prep_blocks, d_moment);
-    const uint32_t out_groups = (hp.n_units + LH_THREADS / 64 - 1) / (LH_THREADS / 64);
-    const uint32_t affine = (hp.n_slices >= 8 && tuning().lamb_oct_affine != 0) ? 1u : 0u;
-    const dim3 grid(out_groups * (affine ? (hp.n_slices + 7) / 8 * 8 : hp.n_slices));
+    const uint32_t out_groups = hp.n_units;
+    const uint32_t affine = (hp.n_runs >= 8 && tuning().lamb_oct_affine != 0) ? 1u : 0u;
+    const dim3 grid(out_groups * (affine ? (hp.n_runs + 7) / 8 * 8 : hp.n_runs));
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (d_counts)
         lh_pairs<true><<<grid, LH_THREADS, 0, stream>>>((const float4*)d_rec, hp.n_rec, hp.slice_len, hp.n_slices, out_size,
-            d_units, hp.n_units, out_groups, affine, out_begin, out_count, d_slices, d_counts);
+            d_units, hp.n_units, out_groups, affine, out_begin, out_count, d_runs, d_counts);
     else
         lh_pairs<false><<<grid, LH_THREADS, 0, stream>>>((const float4*)d_rec, hp.n_rec, hp.slice_len, hp.n_slices, out_size,
-            d_units, hp.n_units, out_groups, affine, out_begin, out_count, d_slices, d_counts);
+            d_units, hp.n_units, out_groups, affine, out_begin, out_count, d_runs, d_counts);
     if (ev1) (void)hipEventRecord(ev1, stream);
-    lh_reduce<<<dim3((hex_local / 4 + 255) / 256, LH_SUMS, hp.n_runs), 256, 0, stream>>>(d_slices, hp.n_slices, hex_local, d_runs);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);      // cube.cpp:126
     lh_final<<<hp.n_units, 64 * LH_FINAL_PARTS, 0, stream>>>(d_runs, hp.n_runs, d_moment, out_size, d_units, hp.n_units,
                                                             out_begin, out_count, scale, (double)tuning().lamb_split_limit,

@@ -208,13 +208,13 @@ __device__ __forceinline__ void ls_rec_wait(LsRec& r) {
 #define LS_MIN_WAVES 2      // workgroups of 4 waves per CU x ... : 8 waves per SIMD fit the registers
 #endif
 
-// Blocks of two records that a wave touches ahead of its scalar loads (0: none).  With few output
+// The waves touch blocks of two records ahead of their scalar loads (0: they do not).  With few output
 // blocks per slice (one shard of eight has 6) every wave of a slice reaches a new cache line at about
 // the same time and all of them wait out its way from memory; the scalar loads are only one block
 // ahead.  Measured on the 1024 -> 128 cube: an eighth 0.646 -> 0.546 ms with 333 slices, 0.544 ->
 // 0.526 with 424; a quarter 1.011 -> 0.984; the whole cube unchanged.
 #ifndef LS_PREFETCH
-#define LS_PREFETCH 8
+#define LS_PREFETCH 1
 #endif
 // COUNT: the wavefronts also count the records they walk (what the arithmetic executed is priced by).
 template <bool COUNT>
@@ -326,18 +326,20 @@ __global__ __launch_bounds__(LS_THREADS, LS_MIN_WAVES) void ls_pairs(
     LsRec ra, rb;
     const uint32_t last = n_blk - 1u;
 #if LS_PREFETCH
-    // The two blocks LS_PREFETCH blocks ahead are touched with a vector load nobody waits for (its
-    // counter is not the scalar loads'), so that they are in the L2 when the scalar loads ask for them.
-    const uint32_t pf_off = (n_blk > 1u && (tid & 1u)) ? 128u : 0u;
-    const uint32_t pf_last = last > 0u ? last - 1u : 0u;
-    float pf_sink;
+    // Every 64 blocks the wave touches the 64 blocks after those, a lane each, with a load nobody waits for
+    // (its counter is not the scalar loads'), so that they are in the L2 when the scalar loads ask for them:
+    // a load into LDS, which has no destination register that could be handed to another value while the
+    // data is on its way (the words land in s_touch and are never looked at).
+    __shared__ float s_touch[64];
+    typedef __attribute__((address_space(1))) const void* ls_gptr;
+    typedef __attribute__((address_space(3))) void* ls_lptr;
 #endif
     ls_rec_load(ra, rp);
     for (uint32_t e = 0; e < n_blk; e += 2) {
 #if LS_PREFETCH
-        {
-            const float4* pp = rp + (size_t)min(e + (uint32_t)LS_PREFETCH, pf_last) * (2 * LS_REC);
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(pf_sink) : "v"(pf_off), "s"(pp));
+        if ((e & 63u) == 0u) {
+            const float4* pp = rp + (size_t)min(e + 64u + (tid & 63u), last) * (2 * LS_REC);
+            __builtin_amdgcn_global_load_lds((ls_gptr)pp, (ls_lptr)s_touch, 4, 0, 0);
         }
 #endif
         ls_rec_wait(ra);
@@ -350,7 +352,9 @@ __global__ __launch_bounds__(LS_THREADS, LS_MIN_WAVES) void ls_pairs(
     }
     ls_rec_wait(ra);       // nothing is in flight when the wave ends
 #if LS_PREFETCH
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink));
+    // (nothing may still be on its way into the workgroup's LDS when the wave ends)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    { const float seen = s_touch[tid & 63u]; asm volatile("" : : "v"(seen)); }
 #endif
     flush();
 
