@@ -516,13 +516,13 @@ int ibl_last_exact_octets(uint64_t* octets) {
 namespace {
 // The hexadecet form over the n_units units listed in S->units.
 int lambertian_run_hex(const float* d_env, uint32_t in_w, uint32_t out_size, uint32_t n_units,
-                       uint32_t out_begin, uint32_t out_count, float* d_out, hipStream_t s) {
+                       uint32_t out_begin, uint32_t out_count, float* d_out, hipStream_t s, bool every_unit = false) {
     const ibl::LambertianHexPlan hp = ibl::lambertian_hex_plan(in_w, out_size, n_units);
     if (int rc = ensure(S->a, hp.rec_bytes)) return rc;
     if (int rc = ensure(S->partial, hp.work_bytes)) return rc;
     unsigned long long* d_counts = nullptr;
     if (int rc = counts_buffer(s, &d_counts)) return rc;
-    HIP_TRY(ibl::lambertian_hex_launch(hp, d_env, in_w, out_size, (const uint32_t*)S->units.ptr, out_begin, out_count, d_out,
+    HIP_TRY(ibl::lambertian_hex_launch(hp, d_env, in_w, out_size, every_unit ? nullptr : (const uint32_t*)S->units.ptr, out_begin, out_count, d_out,
                                        S->a.ptr, S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
                                        S->timing ? S->ev1 : nullptr, S->timing ? S->ev2 : nullptr,
                                        S->timing ? S->ev3 : nullptr));
@@ -551,14 +551,11 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
     if (use_lamb_hex(in_w, out_size)) {
         // the units of 64 hexadecets that hold a texel of the range; the other members are computed and not stored
         const uint32_t total = ibl::ggx_hex_units_total(out_size);
-        uint32_t n_units = total;
+        if (out_begin == 0 && out_count == n_out)          // the whole cube: every unit, no list
+            return lambertian_run_hex(d_env, in_w, out_size, total, out_begin, out_count, d_out, s, true);
         if (int rc = ensure(S->units, (size_t)total * sizeof(uint32_t))) return rc;
-        if (out_begin == 0 && out_count == n_out) {
-            HIP_TRY(ibl::octet_units_strided_launch(0, 1, total, (uint32_t*)S->units.ptr, s));
-        } else {
-            n_units = ibl::ggx_hex_units_in_range_count(out_size, out_begin, out_count);
-            HIP_TRY(ibl::ggx_hex_units_in_range_launch(out_size, out_begin, out_count, (uint32_t*)S->units.ptr, s));
-        }
+        const uint32_t n_units = ibl::ggx_hex_units_in_range_count(out_size, out_begin, out_count);
+        HIP_TRY(ibl::ggx_hex_units_in_range_launch(out_size, out_begin, out_count, (uint32_t*)S->units.ptr, s));
         if (n_units == 0) { S->timed_valid = false; return IBL_OK; }
         return lambertian_run_hex(d_env, in_w, out_size, n_units, out_begin, out_count, d_out, s);
     }
@@ -621,6 +618,7 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
         S->last_counts[2] = 0;
         S->counts_pending = 0;
         if (mine == 0) { S->timed_valid = false; return IBL_OK; }
+        if (n_shards == 1) return lambertian_run_hex(d_env, in_w, out_size, mine, 0, n_out, d_out, pick(stream), true);
         if (int rc = ensure(S->units, (size_t)mine * sizeof(uint32_t))) return rc;
         HIP_TRY(ibl::octet_units_strided_launch(shard, n_shards, mine, (uint32_t*)S->units.ptr, pick(stream)));
         return lambertian_run_hex(d_env, in_w, out_size, mine, 0, n_out, d_out, pick(stream));

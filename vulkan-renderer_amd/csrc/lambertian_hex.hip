@@ -59,13 +59,16 @@ __device__ __forceinline__ double lh_sign(uint32_t k, uint32_t s) { return (__po
 // Record (32 floats): g.x g.y g.z 0 | k = 0: (L0+L1, L0-L1) x RGB | k = 3: the same | k = 5: (L0, L1) x RGB |
 // k = 6: (L0, L1) x RGB | 0 0 0 0, with L0, L1 the transforms of the radiance of the octet and of its partner
 // (0 for a hexadecet on the diagonal, which is its own partner).
+// (The kernel also clears the call's marks: n_flags words.)
 __global__ __launch_bounds__(256) void lh_prep(const float4* __restrict__ env, uint32_t w, uint32_t n_rec,
-                                                float4* __restrict__ rec, double* __restrict__ moment_parts) {
+                                                float4* __restrict__ rec, double* __restrict__ moment_parts,
+                                                uint32_t* __restrict__ flags, uint32_t n_flags) {
     // (one buffer for both uses: the records on their way out, then the moment's tree)
     __shared__ float4 s_rec[256 * (LH_REC + 1)];
     double (*s_m)[256] = (double (*)[256])s_rec;
     const uint32_t tid = threadIdx.x;
     const uint32_t k = blockIdx.x * blockDim.x + tid;
+    for (uint32_t i = k; i < n_flags; i += gridDim.x * blockDim.x) flags[i] = 0u;
     double m[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) m[q] = 0.0;
@@ -474,8 +477,8 @@ hipError_t lambertian_hex_launch(const LambertianHexPlan& hp, const float* d_env
     char* d_sums = (char*)d_work + lambertian_split_header_bytes(op.n_oct_in, op.out_blocks);
     double* d_runs = (double*)d_sums;
 
-    if (hipError_t e = hipMemsetAsync(d_flags, 0, flags_bytes, stream); e != hipSuccess) return e;
-    lh_prep<<<prep_blocks, 256, 0, stream>>>((const float4*)d_env, in_w, hp.n_rec, (float4*)d_rec, d_parts);
+    lh_prep<<<prep_blocks, 256, 0, stream>>>((const float4*)d_env, in_w, hp.n_rec, (float4*)d_rec, d_parts, d_flags,
+                                             op.out_blocks * LH_OCT_BLOCK + op.out_blocks + 1);
     lh_moment<<<1, 256, 0, stream>>>(d_parts, prep_blocks, d_moment);
     const uint32_t out_groups = hp.n_units;
     const uint32_t affine = (hp.n_runs >= 8 && tuning().lamb_oct_affine != 0) ? 1u : 0u;
