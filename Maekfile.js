@@ -99,6 +99,7 @@ const kernels = ['lambertian', 'lambertian_octets', 'ggx', 'ggx_octets', 'ggx_he
 // (the SLP vectoriser turns this kernel's scalar adds into packed adds plus the moves that feed them)
 kernels.push(HIP(`${PKG}/csrc/lambertian_split.hip`, ['-fno-slp-vectorize']));
 kernels.push(HIP(`${PKG}/csrc/lambertian_hex.hip`, ['-fno-slp-vectorize']));
+kernels.push(HIP(`${PKG}/csrc/lambertian_o48.hip`, ['-fno-slp-vectorize']));
 const libibl = LINK(kernels, 'libibl_hip.so', { linker: HIPCC, flags: ['--offload-arch=gfx950', '-shared', '-fPIC'] });
 
 const host = `${PKG}/host`;

@@ -54,7 +54,8 @@ def test_checker_sees_a_register_touched_in_flight():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("source", ["ggx_octets.hip", "ggx_hex.hip", "lambertian_split.hip", "lambertian_hex.hip"])
+@pytest.mark.parametrize("source", ["ggx_octets.hip", "ggx_hex.hip", "lambertian_split.hip", "lambertian_hex.hip",
+                                    "lambertian_o48.hip"])
 def test_hand_written_scalar_loads_are_left_alone(source):
     lines = check_scalar_loads.assembly(os.path.join(CSRC, source))
     loads = 0
@@ -67,7 +68,7 @@ def test_hand_written_scalar_loads_are_left_alone(source):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("source,kernel", [("ggx_octets.hip", "ggx_oct_pairs"), ("lambertian_split.hip", "ls_pairs"),
-                                           ("lambertian_hex.hip", "lh_pairs")])
+                                           ("lambertian_hex.hip", "lh_pairs"), ("lambertian_o48.hip", "lo_pairs")])
 def test_hot_kernels_have_no_scratch(source, kernel):
     extra = ["-fno-slp-vectorize"] if source.startswith("lambertian_") else []
     found = 0
@@ -79,7 +80,8 @@ def test_hot_kernels_have_no_scratch(source, kernel):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("source,kernel", [("lambertian_split.hip", "ls_pairs"), ("lambertian_hex.hip", "lh_pairs")])
+@pytest.mark.parametrize("source,kernel", [("lambertian_split.hip", "ls_pairs"), ("lambertian_hex.hip", "lh_pairs"),
+                                           ("lambertian_o48.hip", "lo_pairs")])
 def test_loads_nobody_waits_for_have_no_destination_register(source, kernel):
     """These kernels touch records ahead with a load that nobody waits for.  Such a load must not name a
     register: its data arrives whenever it arrives, and a compiler that only knows where the instruction

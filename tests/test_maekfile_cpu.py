@@ -26,14 +26,15 @@ def test_dry_run_lists_every_rule(tmp_path):
     lines = r.stdout.strip().splitlines()
     hip = [l for l in lines if "--offload-arch=gfx950" in l and " -c " in l]
     sources = sorted(f for f in os.listdir(os.path.join(ROOT, "vulkan-renderer_amd", "csrc")) if f.endswith(".hip"))
-    assert len(hip) == len(sources) == 13
+    assert len(hip) == len(sources) == 14
     for s in sources:
         assert any(l.rstrip().split(" -o ")[0].endswith(s) for l in hip), s
     assert any("lambertian_split.hip" in l and "-fno-slp-vectorize" in l for l in hip)
     assert any("lambertian_hex.hip" in l and "-fno-slp-vectorize" in l for l in hip)
-    assert sum("-fno-slp-vectorize" in l for l in hip) == 2
+    assert any("lambertian_o48.hip" in l and "-fno-slp-vectorize" in l for l in hip)
+    assert sum("-fno-slp-vectorize" in l for l in hip) == 3
     link_lib = [l for l in lines if "-shared" in l and l.split(" -o ")[1].split()[0].endswith("libibl_hip.so")]
-    assert len(link_lib) == 1 and link_lib[0].count(".o") >= 11
+    assert len(link_lib) == 1 and link_lib[0].count(".o") >= 12
     cube = [l for l in lines if " -o " in l and l.split(" -o ")[1].split()[0].endswith("bin/cube")]
     assert len(cube) == 1 and "-libl_hip" in cube[0] and "-lz" in cube[0]
     assert "vulkan" not in cube[0].replace("vulkan-renderer_amd", "")        # none of the renderer's objects

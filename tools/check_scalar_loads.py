@@ -33,7 +33,7 @@ def sregs(text):
 
 
 def assembly(source):
-    extra = ["-fno-slp-vectorize"] if source.endswith(("lambertian_split.hip", "lambertian_hex.hip")) else []
+    extra = ["-fno-slp-vectorize"] if source.endswith(("lambertian_split.hip", "lambertian_hex.hip", "lambertian_o48.hip")) else []
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
         r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-o", f.name, source], capture_output=True, text=True)
         if r.returncode:

@@ -53,7 +53,7 @@ def resources(source, extra=()):
 def main():
     source = sys.argv[1]
     pattern = sys.argv[2] if len(sys.argv) > 2 else None
-    extra = ["-fno-slp-vectorize"] if source.endswith(("lambertian_split.hip", "lambertian_hex.hip")) else []
+    extra = ["-fno-slp-vectorize"] if source.endswith(("lambertian_split.hip", "lambertian_hex.hip", "lambertian_o48.hip")) else []
     bad = 0
     for k in resources(source, extra):
         spill = k.get("SGPRs Spill", 0), k.get("VGPRs Spill", 0), k.get("ScratchSize [bytes/lane]", 0)

@@ -129,6 +129,11 @@ bool use_lamb_hex(uint32_t in_w, uint32_t out_w) {
         && ibl::lambertian_hex_eligible(in_w, out_w);
 }
 
+// ... over the orbits of the cube's whole symmetry group (lambertian_o48.hip).
+bool use_lamb_o48(uint32_t in_w, uint32_t out_w) {
+    return use_lamb_hex(in_w, out_w) && g_tuning.lamb_o48 != 0 && ibl::lambertian_o48_eligible(in_w, out_w);
+}
+
 void read_tuning_once() {
     if (g_tuning_read) return;
     g_tuning_read = true;
@@ -139,6 +144,7 @@ void read_tuning_once() {
     if (const char* e = getenv("IBL_LAMB_OCT_AFFINE")) g_tuning.lamb_oct_affine = atoi(e);
     if (const char* e = getenv("IBL_LAMB_SPLIT")) g_tuning.lamb_split = atoi(e);
     if (const char* e = getenv("IBL_LAMB_HEX")) g_tuning.lamb_hex = atoi(e);
+    if (const char* e = getenv("IBL_LAMB_O48")) g_tuning.lamb_o48 = atoi(e);
     if (const char* e = getenv("IBL_GGX_WAVES")) g_tuning.ggx_waves = atof(e);
     if (const char* e = getenv("IBL_GGX_XCD_SLICES")) g_tuning.ggx_xcd_slices = atoi(e);
     if (const char* e = getenv("IBL_GGX_CORE")) g_tuning.ggx_core = (float)atof(e);
@@ -355,6 +361,7 @@ int ibl_set_tuning(const char* name, double value) {
     else if (!strcmp(name, "lamb_oct_affine")) g_tuning.lamb_oct_affine = (int)value;
     else if (!strcmp(name, "lamb_split")) g_tuning.lamb_split = (int)value;
     else if (!strcmp(name, "lamb_hex")) g_tuning.lamb_hex = (int)value;
+    else if (!strcmp(name, "lamb_o48")) g_tuning.lamb_o48 = (int)value;
     else if (!strcmp(name, "lamb_split_limit")) g_tuning.lamb_split_limit = (float)value;
     else if (!strcmp(name, "ggx_waves")) g_tuning.ggx_waves = value;
     else if (!strcmp(name, "ggx_xcd_slices")) g_tuning.ggx_xcd_slices = (int)value;
@@ -381,6 +388,7 @@ int ibl_get_tuning(const char* name, double* value) {
     else if (!strcmp(name, "lamb_oct_affine")) *value = g_tuning.lamb_oct_affine;
     else if (!strcmp(name, "lamb_split")) *value = g_tuning.lamb_split;
     else if (!strcmp(name, "lamb_hex")) *value = g_tuning.lamb_hex;
+    else if (!strcmp(name, "lamb_o48")) *value = g_tuning.lamb_o48;
     else if (!strcmp(name, "lamb_split_limit")) *value = g_tuning.lamb_split_limit;
     else if (!strcmp(name, "ggx_waves")) *value = g_tuning.ggx_waves;
     else if (!strcmp(name, "ggx_xcd_slices")) *value = g_tuning.ggx_xcd_slices;
@@ -530,6 +538,22 @@ int lambertian_run_hex(const float* d_env, uint32_t in_w, uint32_t out_size, uin
     finish_timed_call(true);
     return IBL_OK;
 }
+// The 48-fold form over the n_units units listed in S->units.
+int lambertian_run_o48(const float* d_env, uint32_t in_w, uint32_t out_size, uint32_t n_units,
+                       uint32_t out_begin, uint32_t out_count, float* d_out, hipStream_t s, bool every_unit = false) {
+    const ibl::LambertianO48Plan op = ibl::lambertian_o48_plan(in_w, out_size, n_units);
+    if (int rc = ensure(S->a, op.rec_bytes)) return rc;
+    if (int rc = ensure(S->partial, op.work_bytes)) return rc;
+    unsigned long long* d_counts = nullptr;
+    if (int rc = counts_buffer(s, &d_counts)) return rc;
+    HIP_TRY(ibl::lambertian_o48_launch(op, d_env, in_w, out_size, every_unit ? nullptr : (const uint32_t*)S->units.ptr, out_begin, out_count, d_out,
+                                       S->a.ptr, S->partial.ptr, d_counts, s, S->timing ? S->ev0 : nullptr,
+                                       S->timing ? S->ev1 : nullptr, S->timing ? S->ev2 : nullptr,
+                                       S->timing ? S->ev3 : nullptr));
+    S->counts_pending = S->counting ? 2 : 0;
+    finish_timed_call(true);
+    return IBL_OK;
+}
 }  // namespace
 
 int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
@@ -548,6 +572,17 @@ int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_
     S->counts_pending = 0;
     if (out_count == 0) { S->timed_valid = false; return IBL_OK; }
     hipStream_t s = pick(stream);
+    if (use_lamb_o48(in_w, out_size)) {
+        // the units of 64 orbits that hold a texel of the range; the other members are computed and not stored
+        const uint32_t total = ibl::lambertian_o48_units_total(out_size);
+        if (out_begin == 0 && out_count == n_out)          // the whole cube: every unit, no list
+            return lambertian_run_o48(d_env, in_w, out_size, total, out_begin, out_count, d_out, s, true);
+        if (int rc = ensure(S->units, (size_t)total * sizeof(uint32_t))) return rc;
+        const uint32_t n_units = ibl::lambertian_o48_units_in_range_count(out_size, out_begin, out_count);
+        HIP_TRY(ibl::lambertian_o48_units_in_range_launch(out_size, out_begin, out_count, (uint32_t*)S->units.ptr, s));
+        if (n_units == 0) { S->timed_valid = false; return IBL_OK; }
+        return lambertian_run_o48(d_env, in_w, out_size, n_units, out_begin, out_count, d_out, s);
+    }
     if (use_lamb_hex(in_w, out_size)) {
         // the units of 64 hexadecets that hold a texel of the range; the other members are computed and not stored
         const uint32_t total = ibl::ggx_hex_units_total(out_size);
@@ -607,6 +642,21 @@ int ibl_lambertian_shard_dev(const float* d_env, uint32_t in_w, uint32_t in_h, u
         const uint32_t begin = shard * per < n_out ? shard * per : n_out;
         const uint32_t count = per < n_out - begin ? per : n_out - begin;
         return ibl_lambertian_dev(d_env, in_w, in_h, out_size, begin, count, d_out, stream);
+    }
+    if (use_lamb_o48(in_w, out_size)) {
+        // every n_shards-th unit of 64 orbits
+        const uint32_t units = ibl::lambertian_o48_units_total(out_size);
+        const uint32_t mine = shard < units ? (units - shard + n_shards - 1) / n_shards : 0;
+        S->last_counts[0] = 0;
+        S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
+        S->last_counts[1] = (uint64_t)mine * 64 * 48 * in_w * in_h * 6;
+        S->last_counts[2] = 0;
+        S->counts_pending = 0;
+        if (mine == 0) { S->timed_valid = false; return IBL_OK; }
+        if (n_shards == 1) return lambertian_run_o48(d_env, in_w, out_size, mine, 0, n_out, d_out, pick(stream), true);
+        if (int rc = ensure(S->units, (size_t)mine * sizeof(uint32_t))) return rc;
+        HIP_TRY(ibl::octet_units_strided_launch(shard, n_shards, mine, (uint32_t*)S->units.ptr, pick(stream)));
+        return lambertian_run_o48(d_env, in_w, out_size, mine, 0, n_out, d_out, pick(stream));
     }
     if (use_lamb_hex(in_w, out_size)) {
         // every n_shards-th unit of 64 hexadecets (the partition of the 16-fold GGX kernel)
@@ -904,7 +954,13 @@ int ibl_reserve(uint32_t in_w, uint32_t lambertian_size, uint32_t ggx_top_w, uin
     const uint32_t n_in = in_w * in_w * 6;
     if (lambertian_size) {
         if (int rc = check_cube(lambertian_size, lambertian_size, "reserve lambertian output")) return rc;
-        if (use_lamb_hex(in_w, lambertian_size)) {
+        if (use_lamb_o48(in_w, lambertian_size)) {
+            const uint32_t units = ibl::lambertian_o48_units_total(lambertian_size);
+            const ibl::LambertianO48Plan op = ibl::lambertian_o48_plan(in_w, lambertian_size, units);
+            if (int rc = ensure(S->a, op.rec_bytes)) return rc;
+            if (int rc = ensure(S->partial, op.work_bytes)) return rc;
+            if (int rc = ensure(S->units, (size_t)units * sizeof(uint32_t))) return rc;
+        } else if (use_lamb_hex(in_w, lambertian_size)) {
             const uint32_t units = ibl::ggx_hex_units_total(lambertian_size);
             const ibl::LambertianHexPlan hp = ibl::lambertian_hex_plan(in_w, lambertian_size, units);
             if (int rc = ensure(S->a, hp.rec_bytes)) return rc;
@@ -974,7 +1030,8 @@ int shard_map(int kind, uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint3
     m->partition = ibl::SHARD_RANGE;
     m->tw = 1;
     if (kind == IBL_SHARD_LAMBERTIAN) {
-        if (use_lamb_hex(in_w, out_w)) m->partition = ibl::SHARD_GGX_HEX;
+        if (use_lamb_o48(in_w, out_w)) m->partition = ibl::SHARD_LAMB_O48;
+        else if (use_lamb_hex(in_w, out_w)) m->partition = ibl::SHARD_GGX_HEX;
         else if (use_octets(in_w, out_w)) { m->partition = ibl::SHARD_LAMB_OCT; m->tw = ibl::lambertian_oct_tile_edge(out_w); }
     } else {
         if (in_w < 16) return fail(IBL_EINVAL, "ggx: input faces must be at least 16x16 (patch size would be 0), got %u", in_w);

@@ -252,6 +252,43 @@ __host__ __device__ inline uint32_t hex_patches_total(uint32_t pw) {
 }
 __host__ __device__ inline uint32_t hex_swapbits(uint32_t t) { return (t & 4u) | ((t & 1u) << 1) | ((t >> 1) & 1u); }
 
+// ---- orbits of the cube's whole symmetry group ----------------------------------------------------
+// The grids are closed under all six axis permutations as well: a texel direction (c_i, c_j, 1) reaches
+// 48 texels (24 for i = j) under the sign flips and the permutations, an "orbit".  Canonical orbits: the
+// octets (j, i), i <= j, of the +-Z faces, numbered q = j (j + 1) / 2 + i.  lambertian_o48.hip works on them.
+struct O48Lane { uint32_t j, i; bool valid, diagonal; };
+__host__ __device__ inline uint32_t o48_orbits_total(uint32_t w) { return (w / 2) * (w / 2 + 1) / 2; }
+__host__ __device__ inline O48Lane o48_lane(uint32_t q, uint32_t hw) {
+    O48Lane o;
+    o.valid = q < hw * (hw + 1) / 2;
+    tri_decode(o.valid ? q : 0u, o.j, o.i);
+    o.diagonal = o.i == o.j;
+    return o;
+}
+// The same orbits numbered tile by tile (8 x 8 canonical positions, the tiles along the lower triangle; positions
+// above the diagonal of a diagonal tile are no orbits): neighbouring numbers are neighbouring texels on all six
+// faces, which is what a kernel that reads the texels wants.  hw is a multiple of 8.
+__host__ __device__ inline uint32_t o48_tiled_total(uint32_t w) { const uint32_t t = (w / 2) / GH_TILE; return t * (t + 1) / 2 * GH_UNIT; }
+__host__ __device__ inline O48Lane o48_tiled_lane(uint32_t q, uint32_t hw) {
+    const uint32_t t = hw / GH_TILE;
+    O48Lane o;
+    uint32_t tj, ti;
+    const bool inside = q < t * (t + 1) / 2 * GH_UNIT;
+    tri_decode(inside ? q / GH_UNIT : 0u, tj, ti);
+    o.j = tj * GH_TILE + (q % GH_UNIT) / GH_TILE;
+    o.i = ti * GH_TILE + (q % GH_UNIT) % GH_TILE;
+    o.valid = inside && o.i <= o.j;
+    o.diagonal = o.i == o.j;
+    return o;
+}
+// Member m of the orbit of (j, i): bits 0-2 the sign flips, m / 8 the permutation: with n0 = (c_i, c_j, 1) the
+// directions (n0x, n0y, n0z), (n0y, n0x, n0z) on the Z faces, (n0z, n0y, n0x), (n0z, n0x, n0y) on the X faces,
+// (n0x, n0z, n0y), (n0y, n0z, n0x) on the Y faces (getNormalFrom's face table, cube.cpp:35-46).
+__host__ __device__ inline Texel o48_member(uint32_t j, uint32_t i, uint32_t m, uint32_t w) {
+    const uint32_t p = m >> 3, axis = p < 2u ? 2u : (p < 4u ? 0u : 1u);
+    return (p & 1u) ? octet_member(axis, i, j, m & 7u, w, w) : octet_member(axis, j, i, m & 7u, w, w);
+}
+
 // v_add_f32 / v_sub_f32 with the clamp output modifier (result clamped to [0, 1]).
 __device__ __forceinline__ float add_clamp01(float a, float b) {
     return __builtin_amdgcn_fmed3f(a + b, 0.0f, 1.0f);

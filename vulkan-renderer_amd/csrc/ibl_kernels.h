@@ -25,6 +25,7 @@ struct Tuning {
     int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
     int lamb_hex = 1;              // ... over hexadecets (sign flips and the exchange of x and y) where the sizes allow (lambertian_hex.hip)
+    int lamb_o48 = 0;              // ... over the orbits of all 48 symmetries of the cube where lamb_hex applies (lambertian_o48.hip)
     int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
     int ggx_hex = 1;               // ... through the 16-fold symmetry where the sizes allow (ggx_hex.hip; 0: octets)
     int ggx_wg_waves = 0;          // waves (neighbouring units) per workgroup of ggx_hex_pairs: 0 = by input size, 1-4
@@ -92,6 +93,30 @@ struct LambertianHexPlan {
 bool lambertian_hex_eligible(uint32_t in_w, uint32_t out_size);
 LambertianHexPlan lambertian_hex_plan(uint32_t in_w, uint32_t out_size, uint32_t n_units);
 hipError_t lambertian_hex_launch(const LambertianHexPlan& hp, const float* d_env, uint32_t in_w, uint32_t out_size,
+                                 const uint32_t* d_units, uint32_t out_begin, uint32_t out_count, float* d_out,
+                                 void* d_rec, void* d_work, unsigned long long* d_counts, hipStream_t stream,
+                                 hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3);      // d_units null: every unit of the cube
+// The first moment's parts (one per workgroup of a prep kernel, 9 doubles each) added in a fixed order.
+hipError_t lambertian_moment_launch(const double* d_parts, uint32_t n_parts, double* d_moment, hipStream_t stream);
+// lambertian_o48.hip: the split form over the orbits of the cube's whole symmetry group (48 texels: the sign
+// flips and all six axis permutations), with lambertian_octets.hip's kernels behind it for the octets it marks.
+// Output units of 64 orbits, numbered along the lower triangle of the +Z face's first quadrant.
+struct LambertianO48Plan {
+    LambertianOctPlan oct;   // the second pass: the whole cube's octet blocks
+    uint32_t n_rec;          // input records: one per orbit of the input cube
+    uint32_t slice_len, n_slices, n_groups;    // n_groups: groups of slices whose sums a workgroup adds
+    uint32_t n_chunks, chunk_len;              // a slice's records are summed in FP32 over chunks of this length
+    uint32_t n_units;        // output units the call covers
+    size_t recg_offset;      // the weight vectors behind the records
+    size_t rec_bytes;        // the larger of the two passes' records
+    size_t work_bytes;       // header + the larger of the two passes' sums
+};
+bool lambertian_o48_eligible(uint32_t in_w, uint32_t out_size);
+uint32_t lambertian_o48_units_total(uint32_t out_size);
+uint32_t lambertian_o48_units_in_range_count(uint32_t out_w, uint32_t begin, uint32_t count);
+hipError_t lambertian_o48_units_in_range_launch(uint32_t out_w, uint32_t begin, uint32_t count, uint32_t* d_list, hipStream_t stream);
+LambertianO48Plan lambertian_o48_plan(uint32_t in_w, uint32_t out_size, uint32_t n_units);
+hipError_t lambertian_o48_launch(const LambertianO48Plan& op, const float* d_env, uint32_t in_w, uint32_t out_size,
                                  const uint32_t* d_units, uint32_t out_begin, uint32_t out_count, float* d_out,
                                  void* d_rec, void* d_work, unsigned long long* d_counts, hipStream_t stream,
                                  hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3);      // d_units null: every unit of the cube
@@ -192,7 +217,7 @@ hipError_t ggx_hex_launch(const GgxOctPlan& pl, const float* d_env, uint32_t in_
                           float* d_out, void* d_rec, void* d_pn, double* d_partial, unsigned long long* d_counts,
                           hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 // The partition of a cube's output texels into shards (sharding.hip).
-enum ShardPartition { SHARD_RANGE = 0, SHARD_LAMB_OCT = 1, SHARD_GGX_OCT = 2, SHARD_GGX_HEX = 3 };
+enum ShardPartition { SHARD_RANGE = 0, SHARD_LAMB_OCT = 1, SHARD_GGX_OCT = 2, SHARD_GGX_HEX = 3, SHARD_LAMB_O48 = 4 };
 struct ShardMap {
     uint32_t partition;   // ShardPartition
     uint32_t out_w;       // face edge of the cube

@@ -2,7 +2,7 @@
 // ibl_ggx_level_shard_dev use it, and the gather / scatter kernels that move a shard's texels
 // between the full cube and a packed buffer (what an all-gather between GPUs carries).
 //
-// Three partitions:
+// The partitions:
 //   RANGE     contiguous (face, y, x) ranges                     (general kernels)
 //   LAMB_OCT  contiguous ranges of the tile-major octet order, 8 texels per octet
 //                                                                 (Lambertian octet kernel)
@@ -11,6 +11,8 @@
 //                                                                 unit varies over the cube)
 //   GGX_HEX   every n_shards-th unit of 64 hexadecets (16 texels each; lanes and members that
 //             do not exist are padding)                           (GGX 16-fold kernel)
+//   LAMB_O48  every n_shards-th unit of 64 orbits of the cube's whole symmetry group (48 texels
+//             each, 24 on the face diagonals)                     (Lambertian 48-fold kernel)
 // A shard is a list of `per` slots (the same number for every shard, so that the packed
 // buffers of all shards have one size); a slot names a texel or is padding.
 #include "ibl_device.h"
@@ -29,6 +31,10 @@ uint32_t shard_slots(const ShardMap& m) {
         }
         case SHARD_GGX_HEX:
             return (hex_units_total(m.out_w) + m.n_shards - 1) / m.n_shards * GH_UNIT * 16;
+        case SHARD_LAMB_O48: {
+            const uint32_t n_units = (o48_orbits_total(m.out_w) + GH_UNIT - 1) / GH_UNIT;
+            return (n_units + m.n_shards - 1) / m.n_shards * GH_UNIT * 48;
+        }
         default: return (n_out + m.n_shards - 1) / m.n_shards;
     }
 }
@@ -45,6 +51,14 @@ __host__ __device__ inline uint32_t shard_slot_texel(const ShardMap& m, uint32_t
         const uint32_t mem = slot % 16;
         if (!h.valid || (h.diagonal && mem >= 8u)) return 0xffffffffu;
         Texel t = hex_member(h.axis, h.j, h.i, mem, w);
+        return (t.face * w + t.y) * w + t.x;
+    }
+    if (m.partition == SHARD_LAMB_O48) {
+        const uint32_t unit = shard + (slot / (GH_UNIT * 48)) * m.n_shards;
+        const O48Lane ol = o48_lane(unit * GH_UNIT + (slot / 48) % GH_UNIT, hw);
+        const uint32_t mem = slot % 48;
+        if (!ol.valid || (ol.diagonal && ((mem >> 3) & 1u))) return 0xffffffffu;
+        Texel t = o48_member(ol.j, ol.i, mem, w);
         return (t.face * w + t.y) * w + t.x;
     }
     uint32_t oct;
