@@ -56,6 +56,11 @@ LAMB_SPLIT_FLOP_PER_LANE_RECORD = 38
 # adds (4), max, min, max, median for each of the two weight sets (8), 6 packed adds (12), 18 packed
 # FMAs of 2 x 2 flop (72): 101.
 LAMB_HEX_FLOP_PER_LANE_RECORD = 101
+# lo_pairs (the default where the sizes allow: the split over the orbits of all 48 symmetries of the cube,
+# 2304 texel pairs per lane and record) as issued (hipcc -S): 4 packed multiplies and a multiply for the nine
+# products (9), 38 packed adds (76), max, min, max, median for each of the six permutations (24), 4 adds,
+# 98 packed FMAs of 2 x 2 flop (392): 505.
+LAMB_O48_FLOP_PER_LANE_RECORD = 505
 # ggx_oct_pairs per lane, record and pattern: cosine 5 (every record walked); then, for the records
 # evaluated (all of them at narrow lobes; at wide lobes those some lane of the wave accepts):
 # u/t/d 5, rcp + sqrt 2, two clamped ops 2, three multiplies 3, the weight sum's FMA 2 and 12 packed
@@ -147,16 +152,20 @@ class Workload:
             self.hex = (self.split and ibl.get_tuning("lamb_hex") != 0 and ibl.get_tuning("general_only") == 0
                         and self.out_w % 16 == 0 and self.out_w >= 32 and self.in_w % 16 == 0 and self.in_w >= 32
                         and self.in_w & (self.in_w - 1) == 0 and self.out_w & (self.out_w - 1) == 0)
+            # (the 48-fold form serves the same sizes)
+            self.o48 = self.hex and ibl.get_tuning("lamb_o48") != 0
             self.exact_octets = ibl.last_exact_octets() if self.split else None
             if c["wave_records"] and self.split:
-                self.executed_flop_per_launch = 64.0 * c["wave_records"] * (LAMB_HEX_FLOP_PER_LANE_RECORD if self.hex
-                                                                            else LAMB_SPLIT_FLOP_PER_LANE_RECORD)
+                self.executed_flop_per_launch = 64.0 * c["wave_records"] * (
+                    LAMB_O48_FLOP_PER_LANE_RECORD if self.o48 else
+                    LAMB_HEX_FLOP_PER_LANE_RECORD if self.hex else LAMB_SPLIT_FLOP_PER_LANE_RECORD)
                 self.patterns_per_record = None
             elif c["wave_records"]:
                 self.executed_flop_per_launch = 64.0 * (LAMB_FLOP_PER_LANE_RECORD * c["wave_records"]
                                                         + LAMB_FLOP_PER_LANE_PATTERN * c["wave_patterns"])
                 self.patterns_per_record = c["wave_patterns"] / c["wave_records"]
-            self.kernel = ("lh_pairs" if self.hex else "ls_pairs") if self.split else "lambertian_oct_pairs"
+            self.kernel = (("lo_pairs" if self.o48 else "lh_pairs" if self.hex else "ls_pairs") if self.split
+                           else "lambertian_oct_pairs")
             self.desc = ("C%s: Lambertian irradiance %dx%d/face -> %dx%d/face, all (output, input) texel pairs"
                          % (name[1], self.in_w, self.in_w, self.out_w, self.out_w))
             self.bytes_per_launch = 24 * self.n_in + 16 * self.count
@@ -636,7 +645,24 @@ def main():
         finally:
             ibl.set_tuning("lamb_split", 1)
 
-    # ... and on the split form over octets (what the hexadecet form replaced where the sizes allow it).
+    # ... on the split form over hexadecets (16 symmetries, every cosine the reference's to the bit) ...
+    if args.workload == "c4" and not args.no_extras and getattr(wl, "o48", False):
+        ibl.set_tuning("lamb_o48", 0)
+        try:
+            wh = Workload("c4", args, ibl, rank, world, dist)
+            h_elapsed, h_kernel_ms = run_timed(wh, 10, 5, torch, dist, world, ibl.device)
+            if line is not None:
+                line["c4_hexadecets_ms_per_step"] = round(h_elapsed / 10 * 1e3, 4)
+                line["c4_hexadecets_kernel"] = wh.kernel
+                line["c4_hexadecets_kernel_ms"] = round(h_kernel_ms, 4)
+                if wh.executed_flop_per_launch and h_kernel_ms > 0:
+                    line["c4_hexadecets_frac_of_fp32_peak"] = round(
+                        wh.executed_flop_per_launch / (h_kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)
+            del wh
+        finally:
+            ibl.set_tuning("lamb_o48", 1)
+
+    # ... and on the split form over octets (what the two replaced where the sizes allow it).
     if args.workload == "c4" and not args.no_extras and getattr(wl, "hex", False):
         ibl.set_tuning("lamb_hex", 0)
         try:

@@ -44,21 +44,24 @@ def kernel_mode(request, ibl):
     ibl.set_tuning("ggx_hex", 1)
 
 
-@pytest.fixture(params=["hex", "split", "exact", "general"])
+@pytest.fixture(params=["o48", "hex", "split", "exact", "general"])
 def lamb_mode(request, ibl):
-    """The four implementations of the Lambertian integral: the clamped cosine split into its even and
-    odd halves over hexadecets -- the 8 sign flips and the exchange of x and y -- (the default where the
-    output is a multiple of 16 wide and at least 32; octets it cannot hold to ~1e-6 are redone with exact
-    weights), the same split over mirror octets (ibl_set_tuning("lamb_hex", 0); the default at the other
-    even sizes), mirror octets with the reference's per-pair weights throughout ("lamb_split" 0), and
-    the general kernel."""
+    """The five implementations of the Lambertian integral: the clamped cosine split into its even and
+    odd halves over the orbits of all 48 symmetries of the cube -- the 8 sign flips and the 6 axis
+    permutations -- (the default where the faces are multiples of 16 wide and at least 32; octets it
+    cannot hold to ~1e-6 are redone with exact weights), the same split over hexadecets -- the sign
+    flips and the exchange of x and y -- (ibl_set_tuning("lamb_o48", 0)), over mirror octets
+    ("lamb_hex" 0; the default at the other even sizes), mirror octets with the reference's per-pair
+    weights throughout ("lamb_split" 0), and the general kernel."""
     ibl.set_kernel_mode(request.param == "general")
     ibl.set_tuning("lamb_split", 0 if request.param == "exact" else 1)
-    ibl.set_tuning("lamb_hex", 1 if request.param == "hex" else 0)
+    ibl.set_tuning("lamb_hex", 1 if request.param in ("hex", "o48") else 0)
+    ibl.set_tuning("lamb_o48", 1 if request.param == "o48" else 0)
     yield request.param
     ibl.set_kernel_mode(False)
     ibl.set_tuning("lamb_split", 1)
     ibl.set_tuning("lamb_hex", 1)
+    ibl.set_tuning("lamb_o48", 1)
 
 
 def _dev(ibl, arr):

@@ -708,6 +708,26 @@ int ibl_lambertian_static_dev(const float* d_env, uint32_t in_w, uint32_t in_h, 
                     "(both must be even and exactly mirror-symmetric, as every power of two is)", in_w, out_size);
     const uint32_t n_oct = 3 * (out_size / 2) * (out_size / 2);
     const uint32_t n_out = out_size * out_size * 6;
+    if (use_lamb_o48(in_w, out_size)) {
+        // the passes ibl_lambertian_dev runs for these sizes, over every unit of the cube (no list)
+        const ibl::LambertianO48Plan op = ibl::lambertian_o48_plan(in_w, out_size, ibl::lambertian_o48_units_total(out_size));
+        const size_t rec_bytes = (op.rec_bytes + 255) & ~(size_t)255;
+        if (rec_bytes + op.work_bytes > STATIC_SCRATCH_BYTES)
+            return fail(IBL_EINVAL, "lambertian_static: %u x %u/face -> %u x %u/face needs %zu bytes of scratch, the "
+                        "static array holds %zu (e.g. 512 -> 32, 256 -> 64, 128 -> 64 fit); use ibl_lambertian_dev",
+                        in_w, in_w, out_size, out_size, rec_bytes + op.work_bytes, STATIC_SCRATCH_BYTES);
+        S->last_counts[0] = 0;
+        S->last_counts[3] = S->last_counts[4] = S->last_counts[5] = 0;
+        S->last_counts[1] = (uint64_t)n_out * in_w * in_h * 6;
+        S->last_counts[2] = 0;
+        S->counts_pending = 0;
+        unsigned char* base = (unsigned char*)S->static_scratch;
+        HIP_TRY(ibl::lambertian_o48_launch(op, d_env, in_w, out_size, nullptr, 0, n_out, d_out, base, base + rec_bytes, nullptr,
+                                           pick(stream), S->timing ? S->ev0 : nullptr, S->timing ? S->ev1 : nullptr,
+                                           S->timing ? S->ev2 : nullptr, S->timing ? S->ev3 : nullptr));
+        finish_timed_call(true);
+        return IBL_OK;
+    }
     if (use_lamb_hex(in_w, out_size)) {
         // the passes ibl_lambertian_dev runs for these sizes, over every unit of the cube (no list)
         const ibl::LambertianHexPlan hp = ibl::lambertian_hex_plan(in_w, out_size, ibl::ggx_hex_units_total(out_size));

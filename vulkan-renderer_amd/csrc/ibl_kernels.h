@@ -25,7 +25,7 @@ struct Tuning {
     int ggx_early = 1;             // octet GGX kernel, wide lobes: drop records no lane of a wave accepts (0: evaluate all)
     int lamb_split = 1;            // octet Lambertian: even/odd split of the clamped cosine first (0: exact weights only)
     int lamb_hex = 1;              // ... over hexadecets (sign flips and the exchange of x and y) where the sizes allow (lambertian_hex.hip)
-    int lamb_o48 = 0;              // ... over the orbits of all 48 symmetries of the cube where lamb_hex applies (lambertian_o48.hip)
+    int lamb_o48 = 1;              // ... over the orbits of all 48 symmetries of the cube where lamb_hex applies (lambertian_o48.hip; 0: hexadecets)
     int ggx_matrix = 1;            // octet GGX kernel: a walk's sums on the matrix pipe as bf16 pieces (0: vector pipe only)
     int ggx_hex = 1;               // ... through the 16-fold symmetry where the sizes allow (ggx_hex.hip; 0: octets)
     int ggx_wg_waves = 0;          // waves (neighbouring units) per workgroup of ggx_hex_pairs: 0 = by input size, 1-4
