@@ -37,7 +37,8 @@
 //               records with scalar loads: the next record's 72 words are fetched block by block as this
 //               record's multiply-adds let go of them, while the vector pipe already prepares the next
 //               record's weights.  FP32 sums over a chunk of <= 320 records; at the end of a chunk the four
-//               waves' sums meet in LDS and each wave adds 18 of the 72 in FP64.
+//               waves' sums meet in LDS and each wave adds 18 of the 72 in FP64; a group's sums leave as FP32 (one
+//               rounding of 2^-25 each, 128 groups: nothing next to the FP32 sums they come from).
 //   lo_reduce   all groups of a unit in FP64.
 //   lo_final    inverse transforms, the odd half, the scale, the cancellation measured
 //               per texel; marks are set per OCTET in the numbering of lambertian_octets.hip, whose kernels
@@ -112,8 +113,7 @@ __global__ __launch_bounds__(LO_PREP_THREADS) void lo_prep(const float4* __restr
                 lv[s] = 0.0f;
                 if (!(ol.diagonal && (p & 1))) {                  // (on a diagonal the odd-numbered members are the even-numbered ones)
                     Texel t = o48_member(ol.j, ol.i, (uint32_t)p * 8u + s, w);
-                    const float4 v = env[(t.face * w + t.y) * w + t.x];        // cube.cpp:104 row stride (square faces)
-                    lv[s] = ch == 0 ? v.x : (ch == 1 ? v.y : v.z);
+                    lv[s] = ((const float*)env)[(size_t)((t.face * w + t.y) * w + t.x) * 4u + (uint32_t)ch];      // cube.cpp:104 row stride (square faces)
                 }
             }
             double lh[4];
@@ -303,12 +303,14 @@ __device__ __forceinline__ bool lo_lane_wanted(const O48Lane& ol, uint32_t out_s
     return wanted;
 }
 
-// COUNT: the wavefronts also count the records they walk.
-template <bool COUNT>
+// COUNT: the wavefronts also count the records they walk.  MULTI: a slice is more than one chunk, so the waves
+// keep FP64 totals between the chunks (36 registers that the single-chunk form -- inputs up to 1024 x 1024 faces --
+// does without: 4 waves per SIMD instead of 3).
+template <bool COUNT, bool MULTI>
 __global__ __launch_bounds__(LO_THREADS, LO_MIN_WAVES) void lo_pairs(
     const float* __restrict__ rec, const float4* __restrict__ recg, uint32_t n_rec_in, uint32_t slice_len, uint32_t n_slices,
     uint32_t chunk_len, uint32_t n_chunks, uint32_t out_size, const uint32_t* __restrict__ units, uint32_t n_units,
-    uint32_t xcd_affine, uint32_t out_begin, uint32_t out_count, double* __restrict__ partial,
+    uint32_t xcd_affine, uint32_t out_begin, uint32_t out_count, float* __restrict__ partial,
     unsigned long long* __restrict__ counts) {
     // The workgroup: one output unit, LO_RUN consecutive slices, a wave each.
     __shared__ float s_c[LO_RUN][LO_SUMS / 2][64];
@@ -337,11 +339,11 @@ __global__ __launch_bounds__(LO_THREADS, LO_MIN_WAVES) void lo_pairs(
     // FP32 sums of a chunk, pair P: k = 0 (sum, parity sum) of channel P for P < 3; row i of the 2 x 2 product of
     // channel ch at 3 + 2 ch + i; (sum, difference) of the 3 x 3 products at 9 + 9 ch + 3 a + b.
     lo_f32x2 acc[LO_SUMS / 2];
-    double dtot[LO_OWN];
+    double dtot[MULTI ? LO_OWN : 1];
 #pragma unroll
     for (int k = 0; k < LO_SUMS / 2; k++) acc[k] = lo_f32x2{0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < LO_OWN; k++) dtot[k] = 0.0;
+    for (int k = 0; k < (MULTI ? LO_OWN : 1); k++) dtot[k] = 0.0;
 
     const uint32_t in0 = min(n_rec_in, slice * slice_len);
     const uint32_t in1 = min(n_rec_in, in0 + slice_len);
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_MIN_WAVES) void lo_pairs(
     LoRec r;
     lo_u32x4 ga, gb;
     LoWeights W;
-    for (uint32_t ck = 0; ck < n_chunks; ck++) {
+    for (uint32_t ck = 0; ck < (MULTI ? n_chunks : 1u); ck++) {
         const uint32_t c0 = min(n_slice_rec, ck * chunk_len);
         const uint32_t n_here = min(n_slice_rec - c0, chunk_len);
         if (n_here) {
@@ -452,10 +454,15 @@ __global__ __launch_bounds__(LO_THREADS, LO_MIN_WAVES) void lo_pairs(
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < LO_OWN / 2; k++) {
-                double v = dtot[(LO_OWN / 2) * h + k];
+                double v = MULTI ? dtot[MULTI ? (LO_OWN / 2) * h + k : 0] : 0.0;
 #pragma unroll
                 for (int x = 0; x < LO_RUN; x++) v += (double)s_c[x][(LO_OWN / 2) * wave + k][lane];
-                dtot[(LO_OWN / 2) * h + k] = v;
+                if (MULTI) {
+                    dtot[MULTI ? (LO_OWN / 2) * h + k : 0] = v;
+                } else if (ol.valid) {          // the only chunk: the group's sum
+                    const uint32_t q = (uint32_t)(LO_SUMS / 2) * h + (uint32_t)(LO_OWN / 2) * wave + k;
+                    partial[((size_t)sg * LO_SUMS + q) * lanes_local + lo] = (float)v;
+                }
             }
             __syncthreads();
         }
@@ -468,13 +475,13 @@ __global__ __launch_bounds__(LO_THREADS, LO_MIN_WAVES) void lo_pairs(
     { const float seen = s_touch[lane]; asm volatile("" : : "v"(seen)); }
 #endif
 
-    if (ol.valid) {
+    if (MULTI && ol.valid) {
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
             for (int k = 0; k < LO_OWN / 2; k++) {
                 const uint32_t q = (uint32_t)(LO_SUMS / 2) * h + (uint32_t)(LO_OWN / 2) * wave + k;
-                partial[((size_t)sg * LO_SUMS + q) * lanes_local + lo] = dtot[(LO_OWN / 2) * h + k];
+                partial[((size_t)sg * LO_SUMS + q) * lanes_local + lo] = (float)dtot[MULTI ? (LO_OWN / 2) * h + k : 0];
             }
     }
     if (COUNT && lane == 0u) {
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(LO_THREADS, LO_MIN_WAVES) void lo_pairs(
 constexpr int LO_REDUCE_PARTS = 8;
 constexpr int LO_REDUCE_BATCH = 8;
 __global__ __launch_bounds__(64 * LO_REDUCE_PARTS) void lo_reduce(
-    const double* __restrict__ groups, uint32_t n_groups, uint32_t out_size, const uint32_t* __restrict__ units, uint32_t n_units,
+    const float* __restrict__ groups, uint32_t n_groups, uint32_t out_size, const uint32_t* __restrict__ units, uint32_t n_units,
     uint32_t out_begin, uint32_t out_count, double* __restrict__ esum) {
     __shared__ double s_e[LO_REDUCE_PARTS - 1][LO_REDUCE_BATCH][64];
     const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6;
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(64 * LO_REDUCE_PARTS) void lo_reduce(
         for (uint32_t b = part; b < n_groups; b += LO_REDUCE_PARTS) {
 #pragma unroll
             for (int k = 0; k < LO_REDUCE_BATCH; k++)
-                eb[k] += groups[((size_t)b * LO_SUMS + batch * LO_REDUCE_BATCH + k) * lanes_local + lo];
+                eb[k] += (double)groups[((size_t)b * LO_SUMS + batch * LO_REDUCE_BATCH + k) * lanes_local + lo];
         }
     if (part > 0) {
 #pragma unroll
@@ -656,11 +663,11 @@ LambertianO48Plan lambertian_o48_plan(uint32_t in_w, uint32_t out_size, uint32_t
     op.oct = lambertian_oct_plan(in_w, lambertian_oct_blocks_total(out_size));
     op.oct.run = op.oct.n_slices > 1;        // the second pass in its run form (see lambertian_hex_plan)
     op.n_rec = o48_tiled_total(in_w);
-    // Up to 512 slices (as lambertian_hex.hip on the 1024 -> 128 cube), fewer where the cube's output units alone
+    // Up to 640 slices (1024 -> 128: 512 slices 1.452 ms a call, 640 to 1024 1.441 to 1.447, 1280 1.476), fewer where the cube's output units alone
     // make tens of thousands of waves: every group of 4 slices writes 72 FP64 sums per output orbit.
     const uint32_t units_cube = lambertian_o48_units_total(out_size);
     uint32_t want = 32768u / units_cube;
-    want = want < 8u ? 8u : (want > 512u ? 512u : want);
+    want = want < 8u ? 8u : (want > 640u ? 640u : want);
     if (want > op.n_rec / 64u) want = op.n_rec / 64u ? op.n_rec / 64u : 1u;     // (small inputs: 64 records a slice at least)
     if (tuning().lamb_oct_slices) want = tuning().lamb_oct_slices;          // tuning knob
     op.slice_len = (op.n_rec + want - 1) / want;
@@ -678,7 +685,7 @@ LambertianO48Plan lambertian_o48_plan(uint32_t in_w, uint32_t out_size, uint32_t
     const size_t own_rec = op.recg_offset + (size_t)op.n_rec * sizeof(float4);
     op.rec_bytes = own_rec > op.oct.rec_bytes ? own_rec : op.oct.rec_bytes;
     const size_t sums = (size_t)LO_SUMS * n_units * GH_UNIT;
-    const size_t fast = sums * sizeof(double) * (op.n_groups + 1);        // the groups' sums, then their sum
+    const size_t fast = sums * (sizeof(float) * op.n_groups + sizeof(double));        // the groups' sums (FP32), then their sum
     const size_t exact = (size_t)24 * op.oct.out_blocks * LO_OCT_BLOCK
                          * (sizeof(double) * op.oct.n_runs + (op.oct.run ? 0 : sizeof(float) * op.oct.n_slices));
     op.work_bytes = lambertian_split_header_bytes(op.oct.n_oct_in, op.oct.out_blocks) + (fast > exact ? fast : exact);
@@ -699,7 +706,7 @@ hipError_t lambertian_o48_launch(const LambertianO48Plan& op, const float* d_env
     double* d_moment = (double*)((char*)d_work + flags_bytes);
     double* d_parts = (double*)((char*)d_work + flags_bytes + 256);
     char* d_sums = (char*)d_work + lambertian_split_header_bytes(oc.n_oct_in, oc.out_blocks);
-    double* d_groups = (double*)d_sums;
+    float* d_groups = (float*)d_sums;
     float* d_recl = (float*)d_rec;
     float4* d_recg = (float4*)((char*)d_rec + op.recg_offset);
 
@@ -709,15 +716,15 @@ hipError_t lambertian_o48_launch(const LambertianO48Plan& op, const float* d_env
     const uint32_t affine = (op.n_groups >= 8 && tuning().lamb_oct_affine != 0) ? 1u : 0u;
     const dim3 grid(op.n_units * (affine ? (op.n_groups + 7) / 8 * 8 : op.n_groups));
     if (ev0) (void)hipEventRecord(ev0, stream);
-    if (d_counts)
-        lo_pairs<true><<<grid, LO_THREADS, 0, stream>>>(d_recl, d_recg, op.n_rec, op.slice_len, op.n_slices, op.chunk_len, op.n_chunks,
+    auto launch = [&](auto kernel) {
+        kernel<<<grid, LO_THREADS, 0, stream>>>(d_recl, d_recg, op.n_rec, op.slice_len, op.n_slices, op.chunk_len, op.n_chunks,
             out_size, d_units, op.n_units, affine, out_begin, out_count, d_groups, d_counts);
-    else
-        lo_pairs<false><<<grid, LO_THREADS, 0, stream>>>(d_recl, d_recg, op.n_rec, op.slice_len, op.n_slices, op.chunk_len, op.n_chunks,
-            out_size, d_units, op.n_units, affine, out_begin, out_count, d_groups, d_counts);
+    };
+    if (op.n_chunks > 1) { if (d_counts) launch(lo_pairs<true, true>); else launch(lo_pairs<false, true>); }
+    else { if (d_counts) launch(lo_pairs<true, false>); else launch(lo_pairs<false, false>); }
     if (ev1) (void)hipEventRecord(ev1, stream);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);      // cube.cpp:126
-    double* d_esum = d_groups + (size_t)op.n_groups * LO_SUMS * op.n_units * GH_UNIT;
+    double* d_esum = (double*)(d_groups + (size_t)op.n_groups * LO_SUMS * op.n_units * GH_UNIT);
     lo_reduce<<<op.n_units * (LO_SUMS / LO_REDUCE_BATCH), 64 * LO_REDUCE_PARTS, 0, stream>>>(d_groups, op.n_groups, out_size, d_units, op.n_units,
                                                                                             out_begin, out_count, d_esum);
     lo_final<<<op.n_units, 64 * 6, 0, stream>>>(d_esum, d_moment, out_size, d_units, op.n_units,
