@@ -106,17 +106,22 @@ int ibl_ggx_level_plan(uint32_t in_w, uint32_t out_w, uint32_t mip_level, uint32
  * evaluated as the sum of its even and odd halves, and the octets of texels where those halves
  * cancel by more than a factor 16 are recomputed pair by pair with the reference's own weights
  * (see ibl_last_exact_octets): a texel is within ~2e-6 of the reference's double-accumulated
- * sum either way, and exact zeros stay exact.  Where the output is a multiple of 16 wide and at
- * least 32 (and the input a multiple of 16) the split form works on hexadecets -- the 8 sign
- * flips and the exchange of x and y, all of which leave the reference's dot products unchanged to
- * the bit -- and shares its weights between an octet pair and its image (knob "lamb_hex", 1 by
- * default; 0: octets everywhere). */
+ * sum either way, and exact zeros stay exact.  Where both faces are multiples of 16 wide and at
+ * least 32 the split form works on the orbits of the cube's whole symmetry group -- the 8 sign
+ * flips and the 6 axis permutations: 48 texels share six sets of weights, and a Fourier transform
+ * over the group leaves 64 products per channel for the 2304 texel pairs of two orbits (knob
+ * "lamb_o48", 1 by default).  A permuted member's dot product adds the reference's three products
+ * in another order, so single cosines may differ from the reference's in the last bit; with
+ * "lamb_o48" 0 the split form keeps to hexadecets -- the sign flips and the exchange of x and y,
+ * which leave the reference's dot products unchanged to the bit (knob "lamb_hex", 1 by default;
+ * 0: octets everywhere). */
 int ibl_lambertian_dev(const float* d_env, uint32_t in_w, uint32_t in_h, uint32_t out_size,
                        uint32_t out_begin, uint32_t out_count, float* d_out, void* stream);
 
 /* The same integral for shard `shard` of `n_shards`: a library-chosen partition of
  * the output texels that keeps mirror-image texels (+-x, +-y, +-z; with the 16-fold kernels
- * also their images under the exchange of x and y) on one shard, because the kernel evaluates
+ * also their images under the exchange of x and y, with the 48-fold Lambertian kernel under
+ * every axis permutation) on one shard, because the kernel evaluates
  * them together.  Writes that shard's texels into
  * their places in the full-size d_out and touches nothing else; the shards are
  * disjoint and cover the cube, so zero-filled buffers summed over the shards give
@@ -352,7 +357,7 @@ int ibl_set_kernel_mode(int general_only);
 /* Launch-shape knobs of the kernels (slice counts, grid orders; the names are the
  * library's own, the tools under tools/ use them).  They change speed only, except
  * the slice counts, which fix the order of the sums and with it the last bits, and
- * "lamb_split" / "lamb_hex" / "ggx_matrix" / "ggx_hex" / "ggx_few" / "ggx_rsq", which choose between two forms of the arithmetic (see
+ * "lamb_split" / "lamb_hex" / "lamb_o48" / "ggx_matrix" / "ggx_hex" / "ggx_few" / "ggx_rsq", which choose between two forms of the arithmetic (see
  * ibl_lambertian_dev and ibl_ggx_level_dev). */
 int ibl_set_tuning(const char* name, double value);
 /* The current value of a knob ("general_only" reads back ibl_set_kernel_mode). */

@@ -11,16 +11,21 @@ import torch  # noqa: E402
 import vulkan_renderer_amd as vra  # noqa: E402
 
 
-def timed(fn, reps=3):
+def timed(fn, reps=3, burst=1):
+    """Best of `reps` timings of `burst` calls in a row (short calls are timed in bursts, after two untimed ones:
+    a lone millisecond call between two synchronisations runs at whatever clock the idle GPU had)."""
     best = 1e9
     for _ in range(reps):
+        if burst > 1:
+            fn(); fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn()
+        for _ in range(burst):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1))
+        best = min(best, e0.elapsed_time(e1) / burst)
     return best
 
 
@@ -52,7 +57,7 @@ def main():
             ranks = range(n) if (n <= 4 or os.environ.get("SHARD_ALL")) else (0, 3, 7)
             ts, ks = [], []
             for r in ranks:
-                ts.append(timed(lambda: fn(r, n), reps=2 if wl == "c5" else 3))
+                ts.append(timed(lambda: fn(r, n), reps=2 if wl == "c5" else 3, burst=8 if wl == "c4" else 1))
                 try:
                     ks.append(ibl.last_kernel_ms())
                 except vra.capi.IblError:      # this rank owns no block of the level

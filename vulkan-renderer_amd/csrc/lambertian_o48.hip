@@ -724,11 +724,16 @@ hipError_t lambertian_o48_launch(const LambertianO48Plan& op, const float* d_env
     else { if (d_counts) launch(lo_pairs<true, false>); else launch(lo_pairs<false, false>); }
     if (ev1) (void)hipEventRecord(ev1, stream);
     const double scale = 4.0 * 0.31830988618379067154 / ((double)in_w * (double)in_w);      // cube.cpp:126
+    // The limit: lo_final's measure of a texel's cancellation takes the sizes of the ORBIT's transformed sums, which
+    // is about twice what lambertian_split.hip measures on the octet's own two halves, and the sums themselves are
+    // more accurate (a 64 x 64 environment with a light of 1.5e3 ... 3e4 on one face, 32 x 32 out: at twice the
+    // limit 0, 0, 160, 654, 768 octets redone and 1.2e-6 at worst, where the hexadecet form at the limit itself
+    // redoes 0, 322, 608, 703, 758 and is 1.7e-6 off; at four times the limit this form is 4.2e-6 off).
     double* d_esum = (double*)(d_groups + (size_t)op.n_groups * LO_SUMS * op.n_units * GH_UNIT);
     lo_reduce<<<op.n_units * (LO_SUMS / LO_REDUCE_BATCH), 64 * LO_REDUCE_PARTS, 0, stream>>>(d_groups, op.n_groups, out_size, d_units, op.n_units,
                                                                                             out_begin, out_count, d_esum);
     lo_final<<<op.n_units, 64 * 6, 0, stream>>>(d_esum, d_moment, out_size, d_units, op.n_units,
-                                                            out_begin, out_count, scale, (double)tuning().lamb_split_limit,
+                                                            out_begin, out_count, scale, 2.0 * (double)tuning().lamb_split_limit,
                                                             oc.out_blocks, lambertian_oct_tile_edge(out_size), d_flags, d_counts, (float4*)d_out);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     // the marked octets with the reference's own weights (the second pass does not count)
