@@ -328,6 +328,56 @@ def test_lambertian_split_has_room_under_its_limit(ibl, orc):
         ibl.set_counting(False)
 
 
+def test_lambertian_48_fold_kernel_is_the_one_that_runs(ibl, orc):
+    """Where both faces are multiples of 16 wide the split form goes through all 48 symmetries of the cube: the
+    wavefronts walk one record per input ORBIT (24 transformed coefficients each) instead of one per hexadecet (8)
+    or octet, the three forms agree to the rounding of their FP32 sums -- on the face diagonals (orbits of 24
+    texels) as everywhere else -- and sizes the form does not serve stay with the others."""
+    env, env_d = _env(ibl, orc, 128, seed=17)
+    n_in = 6 * 128 * 128
+    try:
+        res = {}
+        for mode, (o48, hexa) in (("o48", (1, 1)), ("hex", (0, 1)), ("oct", (0, 0))):
+            ibl.set_tuning("lamb_o48", o48)
+            ibl.set_tuning("lamb_hex", hexa)
+            ibl.set_counting(True)
+            out = ibl.lambertian(env_d, 64)
+            c = ibl.last_counts()
+            ibl.set_counting(False)
+            assert ibl.torch.equal(out, ibl.lambertian(env_d, 64))           # counting changes no texel
+            res[mode] = (out, c)
+        (a, ca), (b, cb), (o, co) = res["o48"], res["hex"], res["oct"]
+        assert ca["wave_patterns"] == 24 * ca["wave_records"] and cb["wave_patterns"] == 8 * cb["wave_records"]
+        # records walked per wave of 64 outputs: input orbits (tile-numbered: 36 tiles of 64 for 64 x 64 half faces) x
+        # output units against input hexadecets x output units
+        assert ca["wave_records"] == 36 * 64 * 9                             # 528 output orbits = 9 units
+        assert ca["wave_records"] * 48 * 48 * 64 >= 6 * 64 * 64 * n_in       # every texel pair is behind some record
+        assert ca["wave_records"] < 0.2 * cb["wave_records"], (ca, cb)
+        rel = lambda x, y: ((x - y).abs() / y.abs().clamp_min(1e-30))[..., :3]
+        assert float(rel(a, b).max()) < 2e-6 and float(rel(a, o).max()) < 2e-6
+        diag = ibl.torch.arange(64, device=a.device)
+        for face in range(6):                                                # both diagonals of every face
+            assert float(rel(a, b)[face, diag, diag].max()) < 2e-6 and float(rel(a, b)[face, diag, 63 - diag].max()) < 2e-6
+            assert float(a[face, diag, diag, :3].min()) > 0.0
+        _check_cube(orc, a.cpu().numpy(), orc.lambertian(env, 64), label="48-fold kernel, 128 -> 64")
+        # 24 x 24 faces are no multiple of 16: octets there, whatever the knobs say
+        ibl.set_tuning("lamb_o48", 1)
+        ibl.set_tuning("lamb_hex", 1)
+        e, e_d = _env(ibl, orc, 96, seed=18)
+        ibl.set_counting(True)
+        ibl.lambertian(e_d, 24)
+        c1 = ibl.last_counts()
+        ibl.set_tuning("lamb_hex", 0)
+        ibl.lambertian(e_d, 24)
+        c0 = ibl.last_counts()
+        ibl.set_counting(False)
+        assert c1["wave_records"] == c0["wave_records"] and c1["wave_patterns"] == c0["wave_patterns"]
+    finally:
+        ibl.set_counting(False)
+        ibl.set_tuning("lamb_o48", 1)
+        ibl.set_tuning("lamb_hex", 1)
+
+
 def test_lambertian_large_input_subset(ibl, orc, lamb_mode):
     """1024x1024/face input (the headline Lambertian configuration's input), 256 of its 128x128/face
     output texels against the oracle; the full output is covered by
