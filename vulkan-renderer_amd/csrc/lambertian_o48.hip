@@ -663,11 +663,13 @@ LambertianO48Plan lambertian_o48_plan(uint32_t in_w, uint32_t out_size, uint32_t
     op.oct = lambertian_oct_plan(in_w, lambertian_oct_blocks_total(out_size));
     op.oct.run = op.oct.n_slices > 1;        // the second pass in its run form (see lambertian_hex_plan)
     op.n_rec = o48_tiled_total(in_w);
-    // Up to 640 slices (1024 -> 128: 512 slices 1.452 ms a call, 640 to 1024 1.441 to 1.447, 1280 1.476), fewer where the cube's output units alone
-    // make tens of thousands of waves: every group of 4 slices writes 72 FP64 sums per output orbit.
+    // Up to 1024 slices, fewer where the cube's output units alone make tens of thousands of waves: every group of 4
+    // slices writes 72 FP32 sums per output orbit.  1024 -> 128 on one GPU: 512 slices 1.452 ms a call, 640 to 1024
+    // 1.436 to 1.447, 1280 1.473, 2048 1.507; an eighth of that cube (5 of its 33 units: a single round of waves)
+    // 0.351 ms with 640, 0.329 with 896, 0.302 with 1024, 0.324 with 1280 (tools/shard_times.py).
     const uint32_t units_cube = lambertian_o48_units_total(out_size);
-    uint32_t want = 32768u / units_cube;
-    want = want < 8u ? 8u : (want > 640u ? 640u : want);
+    uint32_t want = 65536u / units_cube;
+    want = want < 8u ? 8u : (want > 1024u ? 1024u : want);
     if (want > op.n_rec / 64u) want = op.n_rec / 64u ? op.n_rec / 64u : 1u;     // (small inputs: 64 records a slice at least)
     if (tuning().lamb_oct_slices) want = tuning().lamb_oct_slices;          // tuning knob
     op.slice_len = (op.n_rec + want - 1) / want;
