@@ -39,7 +39,7 @@
 //               record's weights.  FP32 sums over a chunk of <= 320 records; at the end of a chunk the four
 //               waves' sums meet in LDS and each wave adds 18 of the 72 in FP64; a group's sums leave as FP32 (one
 //               rounding of 2^-25 each, 128 groups: nothing next to the FP32 sums they come from).
-//   lo_reduce   all groups of a unit in FP64.
+//   lo_reduce   all groups of a unit in FP64; one workgroup adds the first moment's parts.
 //   lo_final    inverse transforms, the odd half, the scale, the cancellation measured
 //               per texel; marks are set per OCTET in the numbering of lambertian_octets.hip, whose kernels
 //               redo the marked octets.
@@ -491,13 +491,41 @@ __global__ __launch_bounds__(LO_THREADS, LO_MIN_WAVES) void lo_pairs(
 }
 
 // The groups of an output unit added up in FP64, 8 of the 72 sums per workgroup (8 interleaved parts, then
-// those): grid = units x 9, so that a cube of 33 units still spreads over the chip.
+// those): grid = units x 9, so that a cube of 33 units still spreads over the chip -- and one workgroup more, which
+// adds the first moment's parts in a fixed order (a launch of its own costs 6 us of a 1.5 ms call).
 constexpr int LO_REDUCE_PARTS = 8;
 constexpr int LO_REDUCE_BATCH = 8;
 __global__ __launch_bounds__(64 * LO_REDUCE_PARTS) void lo_reduce(
     const float* __restrict__ groups, uint32_t n_groups, uint32_t out_size, const uint32_t* __restrict__ units, uint32_t n_units,
-    uint32_t out_begin, uint32_t out_count, double* __restrict__ esum) {
+    uint32_t out_begin, uint32_t out_count, double* __restrict__ esum,
+    const double* __restrict__ moment_parts, uint32_t n_parts, double* __restrict__ moment) {
     __shared__ double s_e[LO_REDUCE_PARTS - 1][LO_REDUCE_BATCH][64];
+    if (blockIdx.x == n_units * (LO_SUMS / LO_REDUCE_BATCH)) {
+        // the first moment: 9 sums over the prep kernel's workgroups, strided over 256 threads, then a fixed tree
+        double (*s_m)[256] = (double (*)[256])s_e;
+        const uint32_t tid = threadIdx.x;
+        if (tid < 256u) {
+            double m[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) m[k] = 0.0;
+            for (uint32_t p = tid; p < n_parts; p += 256u) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) m[k] += moment_parts[(size_t)p * 9 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) s_m[k][tid] = m[k];
+        }
+        __syncthreads();
+        for (uint32_t step = 128; step > 0; step >>= 1) {
+            if (tid < step) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) s_m[k][tid] += s_m[k][tid + step];
+            }
+            __syncthreads();
+        }
+        if (tid < 9) moment[tid] = s_m[tid][0];
+        return;
+    }
     const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6;
     const uint32_t u = blockIdx.x / (LO_SUMS / LO_REDUCE_BATCH), batch = blockIdx.x % (LO_SUMS / LO_REDUCE_BATCH);
     const uint32_t lo = u * GH_UNIT + lane;
@@ -714,7 +742,6 @@ hipError_t lambertian_o48_launch(const LambertianO48Plan& op, const float* d_env
 
     lo_prep<<<prep_blocks, LO_PREP_THREADS, 0, stream>>>((const float4*)d_env, in_w, op.n_rec, d_recl, d_recg, d_parts, d_flags,
                                                         oc.out_blocks * LO_OCT_BLOCK + oc.out_blocks + 1);
-    if (hipError_t e = lambertian_moment_launch(d_parts, prep_blocks, d_moment, stream); e != hipSuccess) return e;
     const uint32_t affine = (op.n_groups >= 8 && tuning().lamb_oct_affine != 0) ? 1u : 0u;
     const dim3 grid(op.n_units * (affine ? (op.n_groups + 7) / 8 * 8 : op.n_groups));
     if (ev0) (void)hipEventRecord(ev0, stream);
@@ -732,8 +759,8 @@ hipError_t lambertian_o48_launch(const LambertianO48Plan& op, const float* d_env
     // limit 0, 0, 160, 654, 768 octets redone and 1.2e-6 at worst, where the hexadecet form at the limit itself
     // redoes 0, 322, 608, 703, 758 and is 1.7e-6 off; at four times the limit this form is 4.2e-6 off).
     double* d_esum = (double*)(d_groups + (size_t)op.n_groups * LO_SUMS * op.n_units * GH_UNIT);
-    lo_reduce<<<op.n_units * (LO_SUMS / LO_REDUCE_BATCH), 64 * LO_REDUCE_PARTS, 0, stream>>>(d_groups, op.n_groups, out_size, d_units, op.n_units,
-                                                                                            out_begin, out_count, d_esum);
+    lo_reduce<<<op.n_units * (LO_SUMS / LO_REDUCE_BATCH) + 1, 64 * LO_REDUCE_PARTS, 0, stream>>>(d_groups, op.n_groups, out_size, d_units, op.n_units,
+                                                                                                out_begin, out_count, d_esum, d_parts, prep_blocks, d_moment);
     lo_final<<<op.n_units, 64 * 6, 0, stream>>>(d_esum, d_moment, out_size, d_units, op.n_units,
                                                             out_begin, out_count, scale, 2.0 * (double)tuning().lamb_split_limit,
                                                             oc.out_blocks, lambertian_oct_tile_edge(out_size), d_flags, d_counts, (float4*)d_out);
