@@ -96,8 +96,6 @@ hipError_t lambertian_hex_launch(const LambertianHexPlan& hp, const float* d_env
                                  const uint32_t* d_units, uint32_t out_begin, uint32_t out_count, float* d_out,
                                  void* d_rec, void* d_work, unsigned long long* d_counts, hipStream_t stream,
                                  hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev2, hipEvent_t ev3);      // d_units null: every unit of the cube
-// The first moment's parts (one per workgroup of a prep kernel, 9 doubles each) added in a fixed order.
-hipError_t lambertian_moment_launch(const double* d_parts, uint32_t n_parts, double* d_moment, hipStream_t stream);
 // lambertian_o48.hip: the split form over the orbits of the cube's whole symmetry group (48 texels: the sign
 // flips and all six axis permutations), with lambertian_octets.hip's kernels behind it for the octets it marks.
 // Output units of 64 orbits, numbered along the lower triangle of the +Z face's first quadrant.

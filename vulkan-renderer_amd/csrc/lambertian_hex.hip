@@ -170,11 +170,6 @@ __global__ __launch_bounds__(256) void lh_moment(const double* __restrict__ part
     if (tid < 9) moment[tid] = s_m[tid][0];
 }
 
-hipError_t lambertian_moment_launch(const double* d_parts, uint32_t n_parts, double* d_moment, hipStream_t stream) {
-    lh_moment<<<1, 256, 0, stream>>>(d_parts, n_parts, d_moment);
-    return hipGetLastError();
-}
-
 // A record in scalar registers (load and wait written out, as in lambertian_split.hip).
 typedef uint32_t lh_u32x16 __attribute__((ext_vector_type(16)));
 struct LhRec { lh_u32x16 a, b; };
