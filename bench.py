@@ -136,9 +136,9 @@ class Workload:
             self.env = ibl.rgbe_decode(rgbe).reshape(6, self.in_w, self.in_w, 4).contiguous()
             self.n_out = 6 * self.out_w * self.out_w
             self.n_in = 6 * self.in_w * self.in_w
-            n_oct = self.n_out // 8
-            _, oct_count = sharding.shard_range(n_oct, rank, world)
-            self.count = oct_count * 8              # output texels this rank bakes
+            # output texels this rank bakes: the library's partition for these sizes (orbits, hexadecets or octets kept whole)
+            idx = capi.shard_indices(capi.SHARD_LAMBERTIAN, self.in_w, self.out_w, 1, 1, rank, world)
+            self.count = int((idx != 0xFFFFFFFF).sum())
             self.out = t.zeros((6, self.out_w, self.out_w, 4), dtype=t.float32, device=ibl.device)
             self.samples = self.n_out * self.n_in
             self.flop_per_launch = FLOP_PER_LAMBERTIAN_PAIR * self.count * self.n_in
