@@ -26,19 +26,19 @@
 //   * k = xy, xz, yz are permuted among themselves; sums and differences over the two permutations
 //     (one even, one odd) that carry k to k' split them into two 3 x 3 matrix products (27 + 27).
 // The sums and differences ride in the two halves of packed instructions, so a record costs 96 packed
-// multiply-adds and ~70 other vector instructions for 2304 texel pairs (lambertian_hex.hip: 37 for 256).
+// multiply-adds and 76 other vector instructions for 2304 texel pairs (lambertian_hex.hip: 37 for 256).
 // The linear (odd) half of the clamped cosine is the first moment of the input, as in lambertian_split.hip;
 // the marks for texels that cancel too far and their second pass are that file's and lambertian_octets.hip's.
 //
 // Kernel plan
-//   lo_prep     one thread per input orbit: the orbit's transformed radiance (72 floats) and weight vector,
-//               and its share of the first moment.
+//   lo_prep     a workgroup per 64 input orbits, a wave per colour channel: the orbits' transformed radiance
+//               (72 floats) and weight vectors, and their share of the first moment.
 //   lo_pairs    grid = (output units of 64 orbits) x (groups of 4 input slices); a wave per slice walks its
 //               records with scalar loads: the next record's 72 words are fetched block by block as this
 //               record's multiply-adds let go of them, while the vector pipe already prepares the next
 //               record's weights.  FP32 sums over a chunk of <= 320 records; at the end of a chunk the four
 //               waves' sums meet in LDS and each wave adds 18 of the 72 in FP64; a group's sums leave as FP32 (one
-//               rounding of 2^-25 each, 128 groups: nothing next to the FP32 sums they come from).
+//               rounding of 2^-25 each, hundreds of groups: nothing next to the FP32 sums they come from).
 //   lo_reduce   all groups of a unit in FP64; one workgroup adds the first moment's parts.
 //   lo_final    inverse transforms, the odd half, the scale, the cancellation measured
 //               per texel; marks are set per OCTET in the numbering of lambertian_octets.hip, whose kernels
