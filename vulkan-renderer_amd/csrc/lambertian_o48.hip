@@ -74,8 +74,11 @@ __device__ __forceinline__ double lo_sign(uint32_t k, uint32_t s) { return (__po
 
 // Record of an input orbit (72 floats; ch = colour channel):
 //   [2 ch], [2 ch + 1]                 k = 0: sum over the permutations, sum with their parities
-//   [6 + 4 ch + 2 l + j]               k = 0: sum_p L_p R2(P_p)[l][j]
-//   [18 + 18 ch + 2 (3 a + c)], + 1    k = a: L_even(a -> c) + L_odd(a -> c), L_even - L_odd
+//   [6 + 6 l + 2 ch + j]               k = 0: sum_p L_p R2(P_p)[l][j]   (row l of all channels together: the multiply-adds
+//                                      of one row then go to six different sums, and no one waits for the one before)
+//   [18 + 2 (9 c + 3 ch + a)], + 1     k = a: L_even(a -> c) + L_odd(a -> c), L_even - L_odd   (c-major over all channels: a
+//                                      sum is then touched again 27 multiply-adds later, not three; after three or nine the
+//                                      assembler puts a wait state in front of the next one, an issue slot each)
 // and in a separate array the weight vector (g.x, g.y, g.z, g.z).  A workgroup is 64 orbits, a wave per colour
 // channel (24 FP64 sums a thread; one thread for all three channels holds 350 registers and the chip a wave per
 // SIMD).  (The kernel also clears the call's marks.)
@@ -157,13 +160,13 @@ __global__ __launch_bounds__(LO_PREP_THREADS) void lo_prep(const float4* __restr
 #pragma unroll
         for (int l = 0; l < 2; l++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) row[6 + 4 * ch + 2 * l + j] = (float)lr[l][j];
+            for (int j = 0; j < 2; j++) row[6 + 6 * l + 2 * ch + j] = (float)lr[l][j];
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) {
-                row[18 + 18 * ch + 2 * (3 * a + cc)] = (float)la[a][cc][0];
-                row[18 + 18 * ch + 2 * (3 * a + cc) + 1] = (float)la[a][cc][1];
+                row[18 + 2 * (9 * cc + 3 * ch + a)] = (float)la[a][cc][0];
+                row[18 + 2 * (9 * cc + 3 * ch + a) + 1] = (float)la[a][cc][1];
             }
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) s_m[ax * 3 + ch][ql] = m[ax];
@@ -247,7 +250,7 @@ __device__ __forceinline__ void lo_fma_pair(lo_f32x2 (&acc)[LO_SUMS / 2], const 
         asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[PAIR]) : "v"(W.ts), "s"(sp));
     } else if constexpr (PAIR < 9) {
         // row i of the product += f2[i][l] x (row l of the record's matrix)
-        constexpr int ch = (PAIR - 3) / 2, l = (PAIR - 3) % 2;
+        constexpr int l = (PAIR - 3) / 3, ch = (PAIR - 3) % 3;
         if constexpr (l == 0) {
             asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[3 + 2 * ch]) : "v"(W.f2[0]), "s"(sp));
             asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[3 + 2 * ch + 1]) : "v"(W.f2[1]), "s"(sp));
@@ -256,7 +259,7 @@ __device__ __forceinline__ void lo_fma_pair(lo_f32x2 (&acc)[LO_SUMS / 2], const 
             asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[3 + 2 * ch + 1]) : "v"(W.f2[1]), "s"(sp));
         }
     } else {
-        constexpr int ch = (PAIR - 9) / 9, a = ((PAIR - 9) % 9) / 3, cc = (PAIR - 9) % 3;
+        constexpr int cc = (PAIR - 9) / 9, ch = ((PAIR - 9) % 9) / 3, a = (PAIR - 9) % 3;
 #pragma unroll
         for (int b = 0; b < 3; b++)
             asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[9 + 9 * ch + 3 * a + b]) : "v"(W.wa[cc][b]), "s"(sp));
