@@ -33,9 +33,9 @@ def test_shard_range_covers_everything_once():
 
 
 def test_shard_partitions_cover_every_texel_once():
-    """The library's own partitions (host arithmetic of libibl_hip.so, no GPU needed): contiguous
-    octet ranges for Lambertian, strided 64-octet units for GGX, plain ranges where the general
-    kernels serve the sizes."""
+    """The library's own partitions (host arithmetic of libibl_hip.so, no GPU needed): strided units of 64
+    orbits of 48 texels (or contiguous octet ranges, by the kernel that serves the sizes) for Lambertian,
+    strided units of 64 hexadecets or octets for GGX, plain ranges where the general kernels serve the sizes."""
     from vulkan_renderer_amd import capi
     for kind, in_w, out_w, mip, mips in ((capi.SHARD_LAMBERTIAN, 64, 32, 1, 1), (capi.SHARD_GGX, 64, 32, 1, 2),
                                          (capi.SHARD_GGX, 512, 256, 1, 5), (capi.SHARD_LAMBERTIAN, 30, 5, 1, 1),
