@@ -45,13 +45,19 @@ def test_static_scratch_lambertian_equals_the_allocating_entry_point(ibl, orc):
         ibl.set_counting(False)
 
 
+@pytest.mark.parametrize("o48", [1, 0])
 @pytest.mark.parametrize("in_w,out_w", [(512, 32), (256, 64), (128, 64)])
-def test_static_scratch_holds_the_sizes_the_header_names(ibl, orc, in_w, out_w):
+def test_static_scratch_holds_the_sizes_the_header_names(ibl, orc, in_w, out_w, o48):
+    """(In the 48-fold form, the default for these sizes, and in the hexadecet form behind it.)"""
     t = ibl.torch
     env = _env(ibl, orc, in_w, 6)
     got = t.full((6, out_w, out_w, 4), -1.0, dtype=t.float32, device=ibl.device)
-    ibl.lambertian_static(env, out_w, got)
-    assert t.equal(got, ibl.lambertian(env, out_w))
+    ibl.set_tuning("lamb_o48", o48)
+    try:
+        ibl.lambertian_static(env, out_w, got)
+        assert t.equal(got, ibl.lambertian(env, out_w))
+    finally:
+        ibl.set_tuning("lamb_o48", 1)
 
 
 def test_static_scratch_lambertian_rejects_what_does_not_fit(ibl, orc):
